@@ -928,8 +928,80 @@ inline void compute_tcs(const taylor_cfg &cfg, taylor_work &wk, const double st[
     }
 }
 
+// Deterministic pow(x, y) for x > 0 built from IEEE basic operations, fma, frexp,
+// ldexp and rint only (|relative error| < 1e-14 over the range used here). The
+// reference's own pow is library-dependent (SLEEF in heyoka's batch lanes, libm in the
+// scalar remainder), so the step size is not pinned at the last bit anyway; using one
+// spelled-out algorithm here and in the HIP kernel makes substep boundaries agree bit
+// for bit between oracle and GPU.
+inline double det_log(double x)
+{
+    int e;
+    double m = std::frexp(x, &e);
+    if (m < 0.70710678118654752) {
+        m = m * 2.;
+        e -= 1;
+    }
+    const double s = (m - 1.) / (m + 1.);
+    const double s2 = s * s;
+    double p = 1. / 23.;
+    p = std::fma(p, s2, 1. / 21.);
+    p = std::fma(p, s2, 1. / 19.);
+    p = std::fma(p, s2, 1. / 17.);
+    p = std::fma(p, s2, 1. / 15.);
+    p = std::fma(p, s2, 1. / 13.);
+    p = std::fma(p, s2, 1. / 11.);
+    p = std::fma(p, s2, 1. / 9.);
+    p = std::fma(p, s2, 1. / 7.);
+    p = std::fma(p, s2, 1. / 5.);
+    p = std::fma(p, s2, 1. / 3.);
+    p = std::fma(p, s2, 1.);
+    const double at = s * p;
+    return std::fma(static_cast<double>(e), 0.69314718055994530942, 2. * at);
+}
+
+inline double det_exp(double t)
+{
+    const double k = std::rint(t * 1.44269504088896340736);
+    double r = std::fma(-k, 0.693147180369123816490, t);
+    r = std::fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1. / 87178291200.;
+    p = std::fma(p, r, 1. / 6227020800.);
+    p = std::fma(p, r, 1. / 479001600.);
+    p = std::fma(p, r, 1. / 39916800.);
+    p = std::fma(p, r, 1. / 3628800.);
+    p = std::fma(p, r, 1. / 362880.);
+    p = std::fma(p, r, 1. / 40320.);
+    p = std::fma(p, r, 1. / 5040.);
+    p = std::fma(p, r, 1. / 720.);
+    p = std::fma(p, r, 1. / 120.);
+    p = std::fma(p, r, 1. / 24.);
+    p = std::fma(p, r, 1. / 6.);
+    p = std::fma(p, r, 0.5);
+    p = std::fma(p, r, 1.);
+    p = std::fma(p, r, 1.);
+    return std::ldexp(p, static_cast<int>(k));
+}
+
+inline double det_pow(double x, double y)
+{
+    if (!(x > 0.)) {
+        // 0 -> 0 (y > 0 here), NaN -> NaN
+        return x;
+    }
+    if (!(x <= std::numeric_limits<double>::max())) {
+        return x; // +inf
+    }
+    return det_exp(y * det_log(x));
+}
+
 // Jorba-Zou step-size rule as used by heyoka (EXTERNAL).
 // Returns NaN if any of the norms is non-finite.
+inline double rhofac(std::uint32_t p)
+{
+    return std::exp(-0.7 / static_cast<double>(p - 1u)) / (std::exp(1.) * std::exp(1.));
+}
+
 inline double determine_h(const taylor_work &wk)
 {
     const std::uint32_t p = wk.order;
@@ -949,11 +1021,10 @@ inline double determine_h(const taylor_work &wk)
         return std::numeric_limits<double>::quiet_NaN();
     }
     const double num = m0 < 1. ? 1. : m0;
-    const double rho_o = std::pow(num / mo, 1. / static_cast<double>(p));
-    const double rho_om1 = std::pow(num / mom1, 1. / static_cast<double>(p - 1u));
+    const double rho_o = det_pow(num / mo, 1. / static_cast<double>(p));
+    const double rho_om1 = det_pow(num / mom1, 1. / static_cast<double>(p - 1u));
     const double rho_m = std::min(rho_o, rho_om1);
-    const double rhofac = std::exp(-0.7 / static_cast<double>(p - 1u)) / (std::exp(1.) * std::exp(1.));
-    return rho_m * rhofac;
+    return rho_m * rhofac(p);
 }
 
 inline double horner(const double *t, double h, std::uint32_t p)

@@ -494,3 +494,14 @@ void orc_sim_stage_times(void *h, double *out)
 }
 
 } // extern "C"
+
+extern "C" {
+double orc_det_pow(double x, double y)
+{
+    return orc::det_pow(x, y);
+}
+double orc_rhofac(std::uint32_t p)
+{
+    return orc::rhofac(p);
+}
+}
