@@ -1,0 +1,962 @@
+// cascade_amd/csrc/cascade_hip.hip
+//
+// libcascade_hip.so: C ABI (include/cascade_hip.h) over the gfx950 kernels. Unity build:
+// all kernels are compiled in this translation unit.
+//
+//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -fPIC -shared \
+//         -Iinclude cascade_amd/csrc/cascade_hip.hip -o cascade_amd/libcascade_hip.so
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "cascade_hip.h"
+
+#include "dev_math.hpp"
+#include "k_bvh.hpp"
+#include "k_morton.hpp"
+#include "k_narrow.hpp"
+#include "k_propagate.hpp"
+#include "k_scan_sort.hpp"
+
+namespace
+{
+
+std::string g_create_error;
+
+struct dbuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct csc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::map<std::string, dbuf> bufs;
+    int *d_flags = nullptr; // [0] morton non-finite box, [1] dense: no substeps
+    // BVH state of the last csc_bvh_build
+    csc::bvh_bufs bvh{};
+    uint32_t bvh_n = 0, bvh_chunks = 0;
+    // broad phase state
+    uint64_t bp_total = 0;
+    uint32_t bp_n = 0, bp_chunks = 0;
+    std::vector<uint64_t> bp_chunk_off;
+    // narrow phase results (host copies)
+    std::vector<csc_collision> coll;
+    std::vector<csc_conjunction> conj;
+
+    int fail(hipError_t e, const char *what)
+    {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return CSC_ERR_HIP;
+    }
+    int invalid(const char *what)
+    {
+        err = what;
+        return CSC_ERR_INVALID;
+    }
+    // Grow-only named scratch buffer.
+    template <typename T>
+    T *buf(const char *name, size_t count)
+    {
+        auto &b = bufs[name];
+        const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+        if (b.cap < bytes) {
+            if (b.p) {
+                (void)hipStreamSynchronize(stream);
+                (void)hipFree(b.p);
+                b.p = nullptr;
+                b.cap = 0;
+            }
+            const size_t want = bytes + bytes / 4;
+            const hipError_t e = hipMalloc(&b.p, want);
+            if (e != hipSuccess) {
+                err = std::string("hipMalloc(") + name + ", " + std::to_string(want) + "): " + hipGetErrorString(e);
+                return nullptr;
+            }
+            b.cap = want;
+        }
+        return static_cast<T *>(b.p);
+    }
+};
+
+#define CSC_HIP(call)                                                                                                  \
+    do {                                                                                                               \
+        const hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                        \
+            return ctx->fail(e_, #call);                                                                               \
+        }                                                                                                              \
+    } while (0)
+
+#define CSC_LAUNCH_CHECK()                                                                                             \
+    do {                                                                                                               \
+        const hipError_t e_ = hipGetLastError();                                                                       \
+        if (e_ != hipSuccess) {                                                                                        \
+            return ctx->fail(e_, "kernel launch");                                                                     \
+        }                                                                                                              \
+    } while (0)
+
+#define CSC_BUF(var, T, name, count)                                                                                   \
+    T *var = ctx->buf<T>(name, count);                                                                                 \
+    if (!var) {                                                                                                        \
+        return CSC_ERR_HIP;                                                                                            \
+    }
+
+namespace
+{
+
+inline unsigned cdiv(uint64_t a, uint64_t b)
+{
+    return static_cast<unsigned>((a + b - 1) / b);
+}
+
+// ---- small kernels that do not deserve a header ---------------------------------------
+
+struct sum_partial {
+    uint32_t flags, n_nf, nf_idx, n_ste;
+    double nf_time;
+    uint32_t ste_idx, ste_ev;
+    double ste_time;
+    uint64_t nsub;
+};
+
+constexpr int SUM_BLOCK = 256;
+
+__global__ __launch_bounds__(SUM_BLOCK) void k_prop_summary(uint32_t n, const uint32_t *nsub, const int32_t *status,
+                                                            const uint32_t *ev_idx, const double *ev_time,
+                                                            const double *nf_last_t, sum_partial *out)
+{
+    __shared__ sum_partial sh[SUM_BLOCK];
+    sum_partial p;
+    p.flags = 0;
+    p.n_nf = 0;
+    p.nf_idx = 0xffffffffu;
+    p.n_ste = 0;
+    p.nf_time = 0;
+    p.ste_idx = 0xffffffffu;
+    p.ste_ev = 0;
+    p.ste_time = 0;
+    p.nsub = 0;
+    for (uint32_t i = blockIdx.x * SUM_BLOCK + threadIdx.x; i < n; i += gridDim.x * SUM_BLOCK) {
+        const int32_t st = status[i];
+        p.flags |= static_cast<uint32_t>(st) & 0xffffff00u;
+        p.nsub += nsub[i];
+        const int code = st & 0xff;
+        if (code == csc::ST_NF) {
+            const double t = nf_last_t[i];
+            if (p.n_nf == 0 || t < p.nf_time || (t == p.nf_time && i < p.nf_idx)) {
+                p.nf_time = t;
+                p.nf_idx = i;
+            }
+            ++p.n_nf;
+        } else if (code == csc::ST_STE) {
+            const double t = ev_time[i];
+            if (p.n_ste == 0 || t < p.ste_time || (t == p.ste_time && i < p.ste_idx)) {
+                p.ste_time = t;
+                p.ste_idx = i;
+                p.ste_ev = ev_idx[i];
+            }
+            ++p.n_ste;
+        }
+    }
+    sh[threadIdx.x] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < SUM_BLOCK; ++k) {
+            const sum_partial &o = sh[k];
+            p.flags |= o.flags;
+            p.nsub += o.nsub;
+            if (o.n_nf) {
+                if (p.n_nf == 0 || o.nf_time < p.nf_time || (o.nf_time == p.nf_time && o.nf_idx < p.nf_idx)) {
+                    p.nf_time = o.nf_time;
+                    p.nf_idx = o.nf_idx;
+                }
+                p.n_nf += o.n_nf;
+            }
+            if (o.n_ste) {
+                if (p.n_ste == 0 || o.ste_time < p.ste_time || (o.ste_time == p.ste_time && o.ste_idx < p.ste_idx)) {
+                    p.ste_time = o.ste_time;
+                    p.ste_idx = o.ste_idx;
+                    p.ste_ev = o.ste_ev;
+                }
+                p.n_ste += o.n_ste;
+            }
+        }
+        out[blockIdx.x] = p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy_final_state(uint32_t n, const double *fs, double *state)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        state[static_cast<size_t>(i) * 7u + j] = fs[static_cast<size_t>(i) * 6u + j];
+    }
+}
+
+// wl_mask may be null (both whitelists empty); bit 0: in coll whitelist, bit 1: in conj whitelist.
+__global__ __launch_bounds__(256) void k_activity(uint32_t n, const double *state, double min_coll_radius, int with_conj,
+                                                  int coll_wl_empty, int conj_wl_empty, const uint8_t *wl_mask,
+                                                  uint8_t *active)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t m = wl_mask ? wl_mask[i] : 0;
+    const bool coll = (state[static_cast<size_t>(i) * 7u + 6u] > min_coll_radius) && (coll_wl_empty || (m & 1u));
+    const bool conj = with_conj && (conj_wl_empty || (m & 2u));
+    active[i] = static_cast<uint8_t>((coll ? 1u : 0u) | (conj ? 2u : 0u));
+}
+
+csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const double *d_state)
+{
+    csc::prop_params p{};
+    p.state = d_state;
+    p.n = n;
+    p.init_hi = cfg->init_time_hi;
+    p.init_lo = cfg->init_time_lo;
+    p.delta_t = cfg->delta_t;
+    p.ct = cfg->ct;
+    p.nchunks = cfg->nchunks;
+    p.conj_thresh = cfg->conj_thresh;
+    p.mu = cfg->mu;
+    p.rhofac = cfg->rhofac;
+    p.has_exit = cfg->has_exit;
+    p.exit_c0 = cfg->exit_c0;
+    p.has_reentry = cfg->has_reentry;
+    for (int i = 0; i < 3; ++i) {
+        p.re_k[i] = cfg->reentry_k[i];
+    }
+    p.re_c0 = cfg->reentry_c0;
+    p.max_substeps = cfg->max_substeps ? cfg->max_substeps : (1u << 20);
+    return p;
+}
+
+int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
+{
+    if (!cfg) {
+        return ctx->invalid("null configuration");
+    }
+    if (cfg->order != 20u) {
+        ctx->err = "only Taylor order 20 (tol = DBL_EPSILON) is built";
+        return CSC_ERR_UNSUPPORTED;
+    }
+    if (cfg->dyn_kind != CSC_DYN_KEPLER) {
+        ctx->err = "unknown dynamics kind";
+        return CSC_ERR_UNSUPPORTED;
+    }
+    if (cfg->nchunks == 0u || !(cfg->delta_t > 0) || !(cfg->ct > 0)) {
+        return ctx->invalid("invalid superstep configuration");
+    }
+    return CSC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int csc_ctx_create(int device, csc_ctx **out)
+{
+    if (!out) {
+        return CSC_ERR_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return CSC_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "invalid device index";
+        return CSC_ERR_INVALID;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return CSC_ERR_HIP;
+    }
+    auto *ctx = new csc_ctx;
+    ctx->device = device;
+    if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess || (e = hipEventCreate(&ctx->ev0)) != hipSuccess
+        || (e = hipEventCreate(&ctx->ev1)) != hipSuccess || (e = hipMalloc(&ctx->d_flags, 256)) != hipSuccess
+        || (e = hipMemset(ctx->d_flags, 0, 256)) != hipSuccess) {
+        g_create_error = std::string("context creation: ") + hipGetErrorString(e);
+        delete ctx;
+        return CSC_ERR_HIP;
+    }
+    *out = ctx;
+    return CSC_OK;
+}
+
+void csc_ctx_destroy(csc_ctx *ctx)
+{
+    if (!ctx) {
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->bufs) {
+        if (kv.second.p) {
+            (void)hipFree(kv.second.p);
+        }
+    }
+    if (ctx->d_flags) {
+        (void)hipFree(ctx->d_flags);
+    }
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *csc_last_error(csc_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int csc_malloc(csc_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    CSC_HIP(hipSetDevice(ctx->device));
+    CSC_HIP(hipMalloc(d_ptr, bytes ? bytes : 256));
+    return CSC_OK;
+}
+
+int csc_free(csc_ctx *ctx, void *d_ptr)
+{
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    CSC_HIP(hipFree(d_ptr));
+    return CSC_OK;
+}
+
+int csc_memcpy_h2d(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    CSC_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    return CSC_OK;
+}
+
+int csc_memcpy_d2h(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    CSC_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    return CSC_OK;
+}
+
+int csc_memcpy_d2d(csc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    CSC_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CSC_OK;
+}
+
+int csc_memset(csc_ctx *ctx, void *d_dst, int value, size_t bytes)
+{
+    CSC_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return CSC_OK;
+}
+
+int csc_sync(csc_ctx *ctx)
+{
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    return CSC_OK;
+}
+
+int csc_timer_begin(csc_ctx *ctx)
+{
+    CSC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return CSC_OK;
+}
+
+int csc_timer_end(csc_ctx *ctx, float *ms)
+{
+    CSC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    CSC_HIP(hipEventSynchronize(ctx->ev1));
+    CSC_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return CSC_OK;
+}
+
+int csc_check_flags(csc_ctx *ctx)
+{
+    int h[2] = {0, 0};
+    CSC_HIP(hipMemcpyAsync(h, ctx->d_flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    if (h[0] || h[1]) {
+        CSC_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(h), ctx->stream));
+    }
+    if (h[0]) {
+        ctx->err = "A global bounding box with non-finite boundaries and/or size was generated";
+        return CSC_ERR_NONFINITE_AABB;
+    }
+    if (h[1]) {
+        ctx->err = "dense_propagate() could not be performed because no timesteps have been taken for a particle";
+        return CSC_ERR_NO_SUBSTEPS;
+    }
+    return CSC_OK;
+}
+
+// ---- K1 / K2 ---------------------------------------------------------------------------
+
+int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
+                  int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
+                  double *d_final_state, float *d_lbs, float *d_ubs)
+{
+    if (const int rc = check_cfg(ctx, cfg)) {
+        return rc;
+    }
+    if (n == 0u) {
+        return ctx->invalid("Cannot integrate a simulation with no particles");
+    }
+    csc::prop_params p = make_prop_params(cfg, n, d_state);
+    p.nsub = d_nsub;
+    p.status = d_status;
+    p.ev_idx = d_ev_idx;
+    p.ev_time = d_ev_time;
+    p.nf_last_t = d_nf_last_t;
+    p.final_state = d_final_state;
+    p.lbs = d_lbs;
+    p.ubs = d_ubs;
+    const bool events = cfg->has_exit || cfg->has_reentry;
+    const dim3 grid(cdiv(n, 64)), block(64);
+    if (events) {
+        hipLaunchKernelGGL((csc::k_propagate<20, true, false>), grid, block, 0, ctx->stream, p);
+    } else {
+        hipLaunchKernelGGL((csc::k_propagate<20, false, false>), grid, block, 0, ctx->stream, p);
+    }
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state,
+                        const uint64_t *d_tc_off, double *d_tcs, double *d_tcoords)
+{
+    if (const int rc = check_cfg(ctx, cfg)) {
+        return rc;
+    }
+    csc::prop_params p = make_prop_params(cfg, n, d_state);
+    p.tc_off = d_tc_off;
+    p.tcs = d_tcs;
+    p.tcoords = d_tcoords;
+    const bool events = cfg->has_exit || cfg->has_reentry;
+    const dim3 grid(cdiv(n, 64)), block(64);
+    if (events) {
+        hipLaunchKernelGGL((csc::k_propagate<20, true, true>), grid, block, 0, ctx->stream, p);
+    } else {
+        hipLaunchKernelGGL((csc::k_propagate<20, false, true>), grid, block, 0, ctx->stream, p);
+    }
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_propagate_summary(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, const int32_t *d_status,
+                          const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,
+                          csc_prop_summary *out)
+{
+    const unsigned nb = std::min(cdiv(n, SUM_BLOCK), 1024u);
+    CSC_BUF(d_part, sum_partial, "sum_partial", nb);
+    hipLaunchKernelGGL(k_prop_summary, dim3(nb), dim3(SUM_BLOCK), 0, ctx->stream, n, d_nsub, d_status, d_ev_idx,
+                       d_ev_time, d_nf_last_t, d_part);
+    CSC_LAUNCH_CHECK();
+    std::vector<sum_partial> h(nb);
+    CSC_HIP(hipMemcpyAsync(h.data(), d_part, nb * sizeof(sum_partial), hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    csc_prop_summary s{};
+    s.nf_idx = 0xffffffffu;
+    s.ste_idx = 0xffffffffu;
+    for (const auto &o : h) {
+        s.flags |= o.flags;
+        s.total_substeps += o.nsub;
+        if (o.n_nf) {
+            if (s.n_nf == 0 || o.nf_time < s.nf_time || (o.nf_time == s.nf_time && o.nf_idx < s.nf_idx)) {
+                s.nf_time = o.nf_time;
+                s.nf_idx = o.nf_idx;
+            }
+            s.n_nf += o.n_nf;
+        }
+        if (o.n_ste) {
+            if (s.n_ste == 0 || o.ste_time < s.ste_time || (o.ste_time == s.ste_time && o.ste_idx < s.ste_idx)) {
+                s.ste_time = o.ste_time;
+                s.ste_idx = o.ste_idx;
+                s.ste_ev_idx = o.ste_ev;
+            }
+            s.n_ste += o.n_ste;
+        }
+    }
+    *out = s;
+    return CSC_OK;
+}
+
+static int scan_impl(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint32_t nseg, uint64_t *d_out64,
+                     uint32_t *d_out32)
+{
+    const unsigned nb = std::max(1u, cdiv(n, csc::SCAN_TILE));
+    CSC_BUF(d_bs, uint64_t, "scan_block_sums", static_cast<size_t>(nb) * nseg);
+    CSC_BUF(d_tot, uint64_t, "scan_totals", nseg);
+    hipLaunchKernelGGL(csc::k_scan_block_sums, dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in, n, d_bs);
+    hipLaunchKernelGGL(csc::k_scan_sums, dim3(nseg), dim3(1024), 0, ctx->stream, d_bs, static_cast<uint64_t>(nb),
+                       d_tot);
+    if (d_out64) {
+        hipLaunchKernelGGL((csc::k_scan_final<uint64_t>), dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in,
+                           n, d_bs, d_out64, d_tot);
+    } else {
+        hipLaunchKernelGGL((csc::k_scan_final<uint32_t>), dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in,
+                           n, d_bs, d_out32, d_tot);
+    }
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_exclusive_scan(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out)
+{
+    return scan_impl(ctx, d_in, n, 1, d_out, nullptr);
+}
+
+int csc_global_aabb(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs, float *d_glb,
+                    float *d_gub)
+{
+    const unsigned nb = std::min(cdiv(n, csc::GA_BLOCK * 4), static_cast<unsigned>(csc::GA_MAX_PARTIAL));
+    CSC_BUF(d_part, float4, "gaabb_partial", static_cast<size_t>(nb) * nchunks * 2u);
+    hipLaunchKernelGGL(csc::k_gaabb_partial, dim3(nb, nchunks), dim3(csc::GA_BLOCK), 0, ctx->stream,
+                       reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n, d_part);
+    hipLaunchKernelGGL(csc::k_gaabb_final, dim3(nchunks), dim3(64), 0, ctx->stream, d_part, nb,
+                       reinterpret_cast<float4 *>(d_glb), reinterpret_cast<float4 *>(d_gub));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+// ---- K3 / K4 ---------------------------------------------------------------------------
+
+int csc_morton_encode(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs,
+                      const float *d_glb, const float *d_gub, uint64_t *d_codes)
+{
+    hipLaunchKernelGGL(csc::k_morton, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n,
+                       reinterpret_cast<const float4 *>(d_glb), reinterpret_cast<const float4 *>(d_gub), d_codes,
+                       ctx->d_flags);
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+// Stable LSD radix sort of (key, value) over bits [0, nbits), nseg segments of n keys each.
+// keys_a/vals_a hold the input (vals_a may be null on input = iota) and are clobbered; the
+// sorted result is left in *keys_res / *vals_res (one of the a/b buffers).
+static int radix_sort(csc_ctx *ctx, uint32_t n, uint32_t nseg, int nbits, uint64_t *keys_a, uint32_t *vals_a,
+                      bool vals_iota, uint64_t *keys_b, uint32_t *vals_b, uint64_t **keys_res, uint32_t **vals_res)
+{
+    const unsigned nblocks = cdiv(n, csc::RS_TILE);
+    CSC_BUF(d_hist, uint32_t, "rs_hist", static_cast<size_t>(nseg) * csc::RS_BINS * nblocks);
+    uint64_t *kin = keys_a, *kout = keys_b;
+    uint32_t *vin = vals_a, *vout = vals_b;
+    bool iota = vals_iota;
+    for (int shift = 0; shift < nbits; shift += 8) {
+        hipLaunchKernelGGL(csc::k_rs_hist, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin, n, shift,
+                           d_hist, nblocks);
+        hipLaunchKernelGGL(csc::k_rs_scan, dim3(nseg), dim3(1024), 0, ctx->stream, d_hist, nblocks);
+        hipLaunchKernelGGL(csc::k_rs_scatter, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
+                           iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks);
+        CSC_LAUNCH_CHECK();
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+        iota = false;
+    }
+    *keys_res = kin;
+    *vals_res = vin;
+    return CSC_OK;
+}
+
+int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_codes, const float *d_lbs,
+                    const float *d_ubs, uint32_t *d_vidx, uint64_t *d_srt_codes, float *d_srt_lbs,
+                    float *d_srt_ubs)
+{
+    const size_t tot = static_cast<size_t>(n) * nchunks;
+    CSC_BUF(d_ka, uint64_t, "sort_keys_a", tot);
+    CSC_BUF(d_va, uint32_t, "sort_vals_a", tot);
+    CSC_BUF(d_vb, uint32_t, "sort_vals_b", tot);
+    CSC_HIP(hipMemcpyAsync(d_ka, d_codes, tot * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    uint64_t *kres;
+    uint32_t *vres;
+    // 8 passes: a -> srt -> a ... ends in a; use d_srt_codes as the b buffer and copy at the end.
+    if (const int rc = radix_sort(ctx, n, nchunks, 64, d_ka, d_va, true, d_srt_codes, d_vb, &kres, &vres)) {
+        return rc;
+    }
+    if (kres != d_srt_codes) {
+        CSC_HIP(hipMemcpyAsync(d_srt_codes, kres, tot * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    CSC_HIP(hipMemcpyAsync(d_vidx, vres, tot * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(csc::k_gather_aabb, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), d_vidx, n,
+                       reinterpret_cast<float4 *>(d_srt_lbs), reinterpret_cast<float4 *>(d_srt_ubs));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+// ---- K5 --------------------------------------------------------------------------------
+
+int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_srt_codes, const float *d_srt_lbs,
+                  const float *d_srt_ubs)
+{
+    if (n == 0u || nchunks == 0u) {
+        return ctx->invalid("empty BVH input");
+    }
+    const uint32_t nn_max = 2u * n - 1u;
+    const size_t cn = static_cast<size_t>(nchunks) * n, cn1 = static_cast<size_t>(nchunks) * (n + 1u),
+                 cnn = static_cast<size_t>(nchunks) * nn_max;
+    csc::bvh_bufs b{};
+    b.n = n;
+    b.nn_max = nn_max;
+    b.codes = d_srt_codes;
+    b.slb = reinterpret_cast<const float4 *>(d_srt_lbs);
+    b.sub = reinterpret_cast<const float4 *>(d_srt_ubs);
+    b.begin_bits = (n <= (1u << 24)) ? 24 : 32;
+#define BB(field, T, count)                                                                                            \
+    {                                                                                                                  \
+        T *p_ = ctx->buf<T>("bvh_" #field, count);                                                                     \
+        if (!p_) {                                                                                                     \
+            return CSC_ERR_HIP;                                                                                        \
+        }                                                                                                              \
+        b.field = p_;                                                                                                  \
+    }
+    BB(head, uint32_t, cn)
+    BB(excl, uint32_t, cn1)
+    BB(run_start, uint32_t, cn1)
+    BB(k_parent, int32_t, cnn)
+    BB(k_left, int32_t, cn)
+    BB(k_right, int32_t, cn)
+    BB(k_first, uint32_t, cn)
+    BB(k_last, uint32_t, cn)
+    BB(k_delta, int32_t, cn)
+    BB(k_depth, uint32_t, cnn)
+    BB(skey_a, uint64_t, cnn)
+    BB(skey_b, uint64_t, cnn)
+    BB(sval_a, uint32_t, cnn)
+    BB(sval_b, uint32_t, cnn)
+    BB(new_of, uint32_t, cnn)
+    BB(level_cnt, uint32_t, static_cast<size_t>(nchunks) * csc::BVH_MAX_LEVELS)
+    BB(level_off, uint32_t, static_cast<size_t>(nchunks) * (csc::BVH_MAX_LEVELS + 1))
+    BB(nb, uint32_t, cnn)
+    BB(ne, uint32_t, cnn)
+    BB(npar, int32_t, cnn)
+    BB(nleft, int32_t, cnn)
+    BB(nlb, float4, cnn)
+    BB(nub, float4, cnn)
+    BB(ndepth, uint32_t, cnn)
+    BB(nsplit, int32_t, cnn)
+    BB(n_nodes, uint32_t, nchunks)
+#undef BB
+    const dim3 gp(cdiv(n, 256), nchunks), gn(cdiv(nn_max, 256), nchunks), blk(256);
+    hipLaunchKernelGGL(csc::k_bvh_heads, gp, blk, 0, ctx->stream, b);
+    if (const int rc = scan_impl(ctx, b.head, n, nchunks, nullptr, b.excl)) {
+        return rc;
+    }
+    hipLaunchKernelGGL(csc::k_bvh_run_start, gp, blk, 0, ctx->stream, b);
+    hipLaunchKernelGGL(csc::k_bvh_karras, gp, blk, 0, ctx->stream, b);
+    hipLaunchKernelGGL(csc::k_bvh_depth, gn, blk, 0, ctx->stream, b);
+    hipLaunchKernelGGL(csc::k_bvh_level_off, dim3(nchunks), dim3(64), 0, ctx->stream, b);
+    CSC_LAUNCH_CHECK();
+    uint64_t *kres;
+    uint32_t *vres;
+    if (const int rc = radix_sort(ctx, nn_max, nchunks, b.begin_bits + 8, b.skey_a, b.sval_a, true, b.skey_b,
+                                  b.sval_b, &kres, &vres)) {
+        return rc;
+    }
+    hipLaunchKernelGGL(csc::k_bvh_newidx, gn, blk, 0, ctx->stream, b, vres);
+    hipLaunchKernelGGL(csc::k_bvh_emit, gn, blk, 0, ctx->stream, b, vres);
+    // Bottom-up refit, one launch per level (children are final when their level is done).
+    const unsigned rg = std::min(cdiv(nn_max, 256), 1024u);
+    for (int level = csc::BVH_MAX_LEVELS - 2; level >= 0; --level) {
+        hipLaunchKernelGGL(csc::k_bvh_refit_level, dim3(rg, nchunks), blk, 0, ctx->stream, b, level);
+    }
+    CSC_LAUNCH_CHECK();
+    ctx->bvh = b;
+    ctx->bvh_n = n;
+    ctx->bvh_chunks = nchunks;
+    return CSC_OK;
+}
+
+int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t cap, uint64_t *n_nodes)
+{
+    if (chunk >= ctx->bvh_chunks) {
+        return ctx->invalid("invalid chunk index");
+    }
+    uint32_t nn = 0;
+    CSC_HIP(hipMemcpyAsync(&nn, ctx->bvh.n_nodes + chunk, sizeof(nn), hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    *n_nodes = nn;
+    if (nn > cap) {
+        return CSC_ERR_OVERFLOW;
+    }
+    static_assert(sizeof(csc_bvh_node) == sizeof(csc::bvh_node_ref), "node layout");
+    hipLaunchKernelGGL(csc::k_bvh_export, dim3(cdiv(nn, 256)), dim3(256), 0, ctx->stream, ctx->bvh, chunk,
+                       reinterpret_cast<csc::bvh_node_ref *>(d_nodes));
+    CSC_LAUNCH_CHECK();
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    return CSC_OK;
+}
+
+// ---- K6 --------------------------------------------------------------------------------
+
+int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                    const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs)
+{
+    if (n != ctx->bvh_n || nchunks > ctx->bvh_chunks) {
+        return ctx->invalid("broad phase does not match the last BVH build");
+    }
+    const size_t cn = static_cast<size_t>(ctx->bvh_chunks) * n;
+    CSC_BUF(d_cnt, uint32_t, "bp_count", cn);
+    CSC_BUF(d_off, uint64_t, "bp_offset", cn + 1u);
+    csc::bp_params q{};
+    q.n = n;
+    q.nn_max = ctx->bvh.nn_max;
+    q.slb = reinterpret_cast<const float4 *>(d_srt_lbs);
+    q.sub = reinterpret_cast<const float4 *>(d_srt_ubs);
+    q.vidx = d_vidx;
+    q.nlb = ctx->bvh.nlb;
+    q.nub = ctx->bvh.nub;
+    q.nleft = ctx->bvh.nleft;
+    q.nb = ctx->bvh.nb;
+    q.ne = ctx->bvh.ne;
+    q.active = d_active;
+    q.count = d_cnt;
+    const dim3 grid(cdiv(n, csc::BP_BLOCK), nchunks), blk(csc::BP_BLOCK);
+    hipLaunchKernelGGL((csc::k_broad_phase<false>), grid, blk, 0, ctx->stream, q);
+    CSC_LAUNCH_CHECK();
+    const uint64_t ntot = static_cast<uint64_t>(nchunks) * n;
+    if (const int rc = scan_impl(ctx, d_cnt, ntot, 1, d_off, nullptr)) {
+        return rc;
+    }
+    // Per-chunk starts + total.
+    ctx->bp_chunk_off.assign(nchunks + 1u, 0);
+    for (uint32_t c = 0; c <= nchunks; ++c) {
+        CSC_HIP(hipMemcpyAsync(&ctx->bp_chunk_off[c], d_off + static_cast<uint64_t>(c) * n, sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = ctx->bp_chunk_off[nchunks];
+    CSC_BUF(d_pairs, uint32_t, "bp_pairs", std::max<uint64_t>(total, 1) * 2u);
+    if (total) {
+        q.offset = d_off;
+        q.pairs = d_pairs;
+        hipLaunchKernelGGL((csc::k_broad_phase<true>), grid, blk, 0, ctx->stream, q);
+        CSC_LAUNCH_CHECK();
+    }
+    ctx->bp_total = total;
+    ctx->bp_n = n;
+    ctx->bp_chunks = nchunks;
+    *n_pairs = total;
+    return CSC_OK;
+}
+
+int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t cap, uint64_t *count)
+{
+    if (chunk >= ctx->bp_chunks) {
+        return ctx->invalid("invalid chunk index");
+    }
+    const uint64_t b = ctx->bp_chunk_off[chunk], e = ctx->bp_chunk_off[chunk + 1u];
+    *count = e - b;
+    const uint64_t ncopy = std::min(cap, e - b);
+    if (ncopy) {
+        const uint32_t *d_pairs = static_cast<const uint32_t *>(ctx->bufs["bp_pairs"].p);
+        CSC_HIP(hipMemcpyAsync(pairs, d_pairs + b * 2u, ncopy * 2u * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    }
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    return CSC_OK;
+}
+
+// ---- K7 --------------------------------------------------------------------------------
+
+static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                       double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                       const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs, const double *d_tcoords,
+                       const uint32_t *d_pairs, const uint64_t *d_bp_off, uint32_t n0, uint64_t npairs,
+                       uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
+{
+    if (order != 20u) {
+        ctx->err = "only Taylor order 20 is built";
+        return CSC_ERR_UNSUPPORTED;
+    }
+    ctx->coll.clear();
+    ctx->conj.clear();
+    *n_coll = 0;
+    *n_conj = 0;
+    if (warn_flags) {
+        *warn_flags = 0;
+    }
+    if (npairs == 0) {
+        return CSC_OK;
+    }
+    CSC_BUF(d_cnt, uint32_t, "np_counters", 4);
+    uint32_t coll_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_coll"].cap / sizeof(csc::coll_rec), 4096));
+    uint32_t conj_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_conj"].cap / sizeof(csc::conj_rec), 4096));
+    uint32_t h[4];
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        CSC_BUF(d_coll, csc::coll_rec, "np_coll", coll_cap);
+        CSC_BUF(d_conj, csc::conj_rec, "np_conj", conj_cap);
+        CSC_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+        csc::np_params q{};
+        q.n = n;
+        q.nchunks = nchunks;
+        q.ct = ct;
+        q.delta_t = delta_t;
+        q.init_hi = init_time_hi;
+        q.init_lo = init_time_lo;
+        q.conj_thresh2 = conj_thresh * conj_thresh;
+        q.state = d_state;
+        q.active = d_active;
+        q.tc_off = d_tc_off;
+        q.tcs = d_tcs;
+        q.tcoords = d_tcoords;
+        q.pairs = d_pairs;
+        q.bp_off = d_bp_off;
+        q.n0 = n0;
+        q.npairs = npairs;
+        q.coll = d_coll;
+        q.conj = d_conj;
+        q.coll_cap = coll_cap;
+        q.conj_cap = conj_cap;
+        q.counters = d_cnt;
+        hipLaunchKernelGGL((csc::k_narrow_phase<20>), dim3(cdiv(npairs, 64)), dim3(64), 0, ctx->stream, q);
+        CSC_LAUNCH_CHECK();
+        CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        if (h[0] <= coll_cap && h[1] <= conj_cap) {
+            ctx->coll.resize(h[0]);
+            ctx->conj.resize(h[1]);
+            if (h[0]) {
+                CSC_HIP(hipMemcpyAsync(ctx->coll.data(), d_coll, h[0] * sizeof(csc::coll_rec), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+            }
+            if (h[1]) {
+                CSC_HIP(hipMemcpyAsync(ctx->conj.data(), d_conj, h[1] * sizeof(csc::conj_rec), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+            }
+            CSC_HIP(hipStreamSynchronize(ctx->stream));
+            // Deterministic container order: (time, i, j).
+            std::sort(ctx->coll.begin(), ctx->coll.end(), [](const csc_collision &a, const csc_collision &b) {
+                return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
+            });
+            std::sort(ctx->conj.begin(), ctx->conj.end(), [](const csc_conjunction &a, const csc_conjunction &b) {
+                return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
+            });
+            *n_coll = h[0];
+            *n_conj = h[1];
+            if (warn_flags) {
+                *warn_flags = h[2];
+            }
+            return CSC_OK;
+        }
+        // Output overflow: grow and run again (results are recomputed from scratch).
+        coll_cap = std::max(coll_cap, h[0] + h[0] / 4u + 16u);
+        conj_cap = std::max(conj_cap, h[1] + h[1] / 4u + 16u);
+    }
+    ctx->err = "narrow phase output overflow";
+    return CSC_ERR_OVERFLOW;
+}
+
+int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                     double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                     const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs, const double *d_tcoords,
+                     uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
+{
+    if (n != ctx->bp_n || nchunks > ctx->bp_chunks) {
+        return ctx->invalid("narrow phase does not match the last broad phase");
+    }
+    // After a terminal-event shrink only the pairs of the surviving chunks are processed.
+    const uint64_t npairs = ctx->bp_chunk_off[nchunks];
+    return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
+                       d_tc_off, d_tcs, d_tcoords, static_cast<const uint32_t *>(ctx->bufs["bp_pairs"].p),
+                       static_cast<const uint64_t *>(ctx->bufs["bp_offset"].p), n, npairs, n_coll, n_conj,
+                       warn_flags);
+}
+
+int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                           double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                           const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs,
+                           const double *d_tcoords, const uint32_t *d_pairs, const uint64_t *pair_off,
+                           uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
+{
+    // Chunk starts with stride 1 (n0 = 1): bp_off[c] = pair_off[c].
+    CSC_BUF(d_off, uint64_t, "np_pair_off", nchunks + 1u);
+    CSC_HIP(hipMemcpyAsync(d_off, pair_off, (nchunks + 1u) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
+                       d_tc_off, d_tcs, d_tcoords, d_pairs, d_off, 1, pair_off[nchunks], n_coll, n_conj, warn_flags);
+}
+
+int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,
+                         uint64_t conj_cap)
+{
+    if (coll && !ctx->coll.empty()) {
+        std::memcpy(coll, ctx->coll.data(), std::min<uint64_t>(coll_cap, ctx->coll.size()) * sizeof(csc_collision));
+    }
+    if (conj && !ctx->conj.empty()) {
+        std::memcpy(conj, ctx->conj.data(), std::min<uint64_t>(conj_cap, ctx->conj.size()) * sizeof(csc_conjunction));
+    }
+    return CSC_OK;
+}
+
+// ---- K8 and helpers --------------------------------------------------------------------
+
+int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, const uint64_t *d_tc_off,
+                        const double *d_tcs, const double *d_tcoords, double *d_out)
+{
+    if (order != 20u) {
+        ctx->err = "only Taylor order 20 is built";
+        return CSC_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((csc::k_dense<20>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, t, d_tc_off, d_tcs,
+                       d_tcoords, d_out, ctx->d_flags + 1);
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_copy_final_state(csc_ctx *ctx, uint32_t n, const double *d_final_state, double *d_state)
+{
+    hipLaunchKernelGGL(k_copy_final_state, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_final_state, d_state);
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_activity_flags(csc_ctx *ctx, uint32_t n, const double *d_state, double min_coll_radius, int with_conj,
+                       const uint64_t *coll_wl, uint64_t n_coll_wl, const uint64_t *conj_wl, uint64_t n_conj_wl,
+                       uint8_t *d_active)
+{
+    const uint8_t *d_mask = nullptr;
+    if (n_coll_wl || n_conj_wl) {
+        std::vector<uint8_t> mask(n, 0);
+        for (uint64_t k = 0; k < n_coll_wl; ++k) {
+            if (coll_wl[k] < n) {
+                mask[coll_wl[k]] |= 1u;
+            }
+        }
+        for (uint64_t k = 0; k < n_conj_wl; ++k) {
+            if (conj_wl[k] < n) {
+                mask[conj_wl[k]] |= 2u;
+            }
+        }
+        CSC_BUF(d_m, uint8_t, "wl_mask", n);
+        CSC_HIP(hipMemcpyAsync(d_m, mask.data(), n, hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        d_mask = d_m;
+    }
+    hipLaunchKernelGGL(k_activity, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_state, min_coll_radius,
+                       with_conj, n_coll_wl == 0 ? 1 : 0, n_conj_wl == 0 ? 1 : 0, d_mask, d_active);
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+} // extern "C"

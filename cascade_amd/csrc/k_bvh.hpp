@@ -1,0 +1,423 @@
+// cascade_amd/csrc/k_bvh.hpp
+//
+// K5: LBVH over the sorted 64-bit Morton codes with EXACTLY the topology, node order and
+// AABBs of the reference's level-synchronous builder, but built in a fixed number of
+// data-parallel passes instead of one pass per tree level.
+//
+// Replaces src/sim_bvh.cpp:89-496 (construct_bvh_trees_parallel). Why the result is the
+// same tree: a reference node covers a sorted range whose codes share all bits above its
+// split_idx; it splits at the first bit >= split_idx where the range is not constant, i.e.
+// at clz(code[first] ^ code[last]), at the first index where that bit is set (:207-240);
+// ranges of equal codes are (multi-particle) leaves (:224-231). That is the binary radix
+// tree over the DISTINCT codes (Karras 2012), with one leaf per run of equal codes. The
+// reference stores nodes level by level, each level ordered by `begin` (children are
+// placed by a prefix sum over the parents in order, :311-327,:360-368), so the canonical
+// index of a node is its rank under the key (depth, begin). Passes:
+//   heads -> scan -> run starts -> Karras internal nodes -> depths (parent walk) ->
+//   stable radix sort by (depth, begin) -> emit nodes (+ leaf AABBs) -> bottom-up refit.
+// Everything is HBM/L2 bound integer work: ~250 B per particle per chunk.
+//
+// Node arrays (structure of arrays, canonical order), per chunk with stride 2N - 1:
+//   nb/ne (u32 begin/end), npar/nleft (i32; right = left + 1), nlb/nub (float4),
+//   ndepth (u32), nsplit (i32: final value of the reference's construction scratch).
+// k_bvh_export packs them into the reference's 60-byte bvh_node
+// (include/cascade/detail/sim_data.hpp:193-207) for parity checks.
+#pragma once
+
+#include "dev_math.hpp"
+
+namespace csc
+{
+
+constexpr int BVH_MAX_LEVELS = 66; // depth <= 64
+
+struct bvh_bufs {
+    std::uint32_t n;        // particles per chunk
+    std::uint32_t nn_max;   // 2n - 1
+    const std::uint64_t *codes; // [C][n] sorted
+    const float4 *slb, *sub;    // [C][n] sorted AABBs
+    // scratch
+    std::uint32_t *head;      // [C][n]
+    std::uint32_t *excl;      // [C][n + 1] (excl[n] = M)
+    std::uint32_t *run_start; // [C][n + 1]
+    std::int32_t *k_parent;   // [C][nn_max] Karras ids: internal i, leaf (M - 1) + r
+    std::int32_t *k_left, *k_right; // [C][n]
+    std::uint32_t *k_first, *k_last; // [C][n] run indices
+    std::int32_t *k_delta;    // [C][n]
+    std::uint32_t *k_depth;   // [C][nn_max]
+    std::uint64_t *skey_a, *skey_b; // [C][nn_max]
+    std::uint32_t *sval_a, *sval_b; // [C][nn_max]
+    std::uint32_t *new_of;    // [C][nn_max]
+    std::uint32_t *level_cnt; // [C][BVH_MAX_LEVELS]
+    std::uint32_t *level_off; // [C][BVH_MAX_LEVELS + 1]
+    // output
+    std::uint32_t *nb, *ne;
+    std::int32_t *npar, *nleft;
+    float4 *nlb, *nub;
+    std::uint32_t *ndepth;
+    std::int32_t *nsplit;
+    std::uint32_t *n_nodes; // [C]
+    int begin_bits;         // 24 or 32
+};
+
+__global__ __launch_bounds__(256) void k_bvh_heads(bvh_bufs b)
+{
+    const std::uint32_t c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) {
+        return;
+    }
+    const std::uint64_t *codes = b.codes + static_cast<std::size_t>(c) * b.n;
+    b.head[static_cast<std::size_t>(c) * b.n + i] = (i == 0 || codes[i] != codes[i - 1]) ? 1u : 0u;
+    if (i < BVH_MAX_LEVELS) {
+        b.level_cnt[c * BVH_MAX_LEVELS + i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bvh_run_start(bvh_bufs b)
+{
+    const std::uint32_t c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) {
+        return;
+    }
+    const std::uint32_t *excl = b.excl + static_cast<std::size_t>(c) * (b.n + 1u);
+    std::uint32_t *rs = b.run_start + static_cast<std::size_t>(c) * (b.n + 1u);
+    if (b.head[static_cast<std::size_t>(c) * b.n + i]) {
+        rs[excl[i]] = i;
+    }
+    if (i == 0) {
+        const std::uint32_t M = excl[b.n];
+        rs[M] = b.n;
+        b.n_nodes[c] = 2u * M - 1u;
+    }
+}
+
+// delta(i, j) over the distinct keys; -1 out of range.
+CSC_DEV int bvh_delta(const std::uint64_t *codes, const std::uint32_t *rs, std::int64_t M, std::uint64_t ki,
+                      std::int64_t j)
+{
+    if (j < 0 || j >= M) {
+        return -1;
+    }
+    const std::uint64_t kj = codes[rs[j]];
+    return __clzll(static_cast<long long>(ki ^ kj));
+}
+
+__global__ __launch_bounds__(256) void k_bvh_karras(bvh_bufs b)
+{
+    const std::uint32_t c = blockIdx.y;
+    const std::int64_t i = static_cast<std::int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const std::uint32_t *excl = b.excl + static_cast<std::size_t>(c) * (b.n + 1u);
+    const std::int64_t M = excl[b.n];
+    const std::uint64_t *codes = b.codes + static_cast<std::size_t>(c) * b.n;
+    const std::uint32_t *rs = b.run_start + static_cast<std::size_t>(c) * (b.n + 1u);
+    std::int32_t *kpar = b.k_parent + static_cast<std::size_t>(c) * b.nn_max;
+    if (M == 1) {
+        if (i == 0) {
+            kpar[0] = -1;
+        }
+        return;
+    }
+    if (i >= M - 1) {
+        return;
+    }
+    const std::size_t o = static_cast<std::size_t>(c) * b.n + i;
+    const std::uint64_t ki = codes[rs[i]];
+    const int dl = bvh_delta(codes, rs, M, ki, i - 1), dr = bvh_delta(codes, rs, M, ki, i + 1);
+    const std::int64_t d = (dr - dl) > 0 ? 1 : -1;
+    const int dmin = (d > 0) ? dl : dr;
+    std::int64_t lmax = 2;
+    while (bvh_delta(codes, rs, M, ki, i + lmax * d) > dmin) {
+        lmax *= 2;
+    }
+    std::int64_t l = 0;
+    for (std::int64_t t = lmax / 2; t >= 1; t /= 2) {
+        if (bvh_delta(codes, rs, M, ki, i + (l + t) * d) > dmin) {
+            l += t;
+        }
+    }
+    const std::int64_t j = i + l * d;
+    const int dnode = bvh_delta(codes, rs, M, ki, j);
+    std::int64_t s = 0;
+    {
+        std::int64_t t = l;
+        do {
+            t = (t + 1) / 2;
+            if (bvh_delta(codes, rs, M, ki, i + (s + t) * d) > dnode) {
+                s += t;
+            }
+        } while (t > 1);
+    }
+    const std::int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+    const std::int64_t first = i < j ? i : j, last = i < j ? j : i;
+    const std::int32_t left = (first == gamma) ? static_cast<std::int32_t>((M - 1) + gamma) : static_cast<std::int32_t>(gamma);
+    const std::int32_t right
+        = (last == gamma + 1) ? static_cast<std::int32_t>((M - 1) + gamma + 1) : static_cast<std::int32_t>(gamma + 1);
+    b.k_left[o] = left;
+    b.k_right[o] = right;
+    b.k_first[o] = static_cast<std::uint32_t>(first);
+    b.k_last[o] = static_cast<std::uint32_t>(last);
+    b.k_delta[o] = dnode;
+    kpar[left] = static_cast<std::int32_t>(i);
+    kpar[right] = static_cast<std::int32_t>(i);
+    if (i == 0) {
+        kpar[0] = -1;
+    }
+}
+
+// Depth by walking the parent chain; sort key (depth, begin); per-level histogram.
+__global__ __launch_bounds__(256) void k_bvh_depth(bvh_bufs b)
+{
+    __shared__ std::uint32_t hist[BVH_MAX_LEVELS];
+    const std::uint32_t c = blockIdx.y;
+    const std::uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < BVH_MAX_LEVELS) {
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const std::uint32_t *excl = b.excl + static_cast<std::size_t>(c) * (b.n + 1u);
+    const std::uint32_t M = excl[b.n];
+    const std::uint32_t nn = 2u * M - 1u;
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
+    if (id < b.nn_max) {
+        std::uint64_t key = ~0ull;
+        if (id < nn) {
+            const std::int32_t *kpar = b.k_parent + no;
+            std::uint32_t depth = 0;
+            std::int32_t p = kpar[id];
+            while (p >= 0) {
+                ++depth;
+                p = kpar[p];
+            }
+            b.k_depth[no + id] = depth;
+            const std::uint32_t *rs = b.run_start + static_cast<std::size_t>(c) * (b.n + 1u);
+            std::uint32_t begin;
+            if (id < M - 1u) {
+                begin = rs[b.k_first[static_cast<std::size_t>(c) * b.n + id]];
+            } else {
+                begin = rs[id - (M - 1u)];
+            }
+            key = (static_cast<std::uint64_t>(depth) << b.begin_bits) | begin;
+            atomicAdd(&hist[depth < BVH_MAX_LEVELS ? depth : BVH_MAX_LEVELS - 1], 1u);
+        }
+        b.skey_a[no + id] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x < BVH_MAX_LEVELS && hist[threadIdx.x]) {
+        atomicAdd(&b.level_cnt[c * BVH_MAX_LEVELS + threadIdx.x], hist[threadIdx.x]);
+    }
+}
+
+__global__ void k_bvh_level_off(bvh_bufs b)
+{
+    const std::uint32_t c = blockIdx.x;
+    if (threadIdx.x == 0) {
+        std::uint32_t run = 0;
+        for (int l = 0; l < BVH_MAX_LEVELS; ++l) {
+            b.level_off[c * (BVH_MAX_LEVELS + 1) + l] = run;
+            run += b.level_cnt[c * BVH_MAX_LEVELS + l];
+        }
+        b.level_off[c * (BVH_MAX_LEVELS + 1) + BVH_MAX_LEVELS] = run;
+    }
+}
+
+// sval: sorted Karras ids.
+__global__ __launch_bounds__(256) void k_bvh_newidx(bvh_bufs b, const std::uint32_t *sval)
+{
+    const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    const std::uint32_t nn = b.n_nodes[c];
+    if (p >= nn) {
+        return;
+    }
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
+    b.new_of[no + sval[no + p]] = p;
+}
+
+__global__ __launch_bounds__(256) void k_bvh_emit(bvh_bufs b, const std::uint32_t *sval)
+{
+    const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    const std::uint32_t nn = b.n_nodes[c];
+    if (p >= nn) {
+        return;
+    }
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
+    const std::size_t po = static_cast<std::size_t>(c) * b.n;
+    const std::uint32_t M = (nn + 1u) / 2u;
+    const std::uint32_t id = sval[no + p];
+    const std::uint32_t *rs = b.run_start + static_cast<std::size_t>(c) * (b.n + 1u);
+    const std::int32_t kp = b.k_parent[no + id];
+    const std::int32_t parent = kp < 0 ? -1 : static_cast<std::int32_t>(b.new_of[no + kp]);
+    // Initial split_idx of the node: parent's final split bit + 1 (root: 0).
+    const int init_split = kp < 0 ? 0 : b.k_delta[po + kp] + 1;
+    const float finf = __builtin_huge_valf();
+    std::uint32_t begin, end;
+    std::int32_t left;
+    int split;
+    float4 lb = make_float4(finf, finf, finf, finf), ub = make_float4(-finf, -finf, -finf, -finf);
+    if (id < M - 1u) {
+        begin = rs[b.k_first[po + id]];
+        end = rs[b.k_last[po + id] + 1u];
+        left = static_cast<std::int32_t>(b.new_of[no + b.k_left[po + id]]);
+        split = b.k_delta[po + id];
+    } else {
+        const std::uint32_t r = id - (M - 1u);
+        begin = rs[r];
+        end = rs[r + 1u];
+        left = -1;
+        // A multi-particle leaf scans the remaining bits up to 63 (src/sim_bvh.cpp:220-240).
+        split = (end - begin > 1u && init_split <= 63) ? 63 : init_split;
+        const float4 *slb = b.slb + po, *sub = b.sub + po;
+        for (std::uint32_t k = begin; k < end; ++k) {
+            const float4 l4 = slb[k], u4 = sub[k];
+            lb = make_float4(fminf_std(lb.x, l4.x), fminf_std(lb.y, l4.y), fminf_std(lb.z, l4.z), fminf_std(lb.w, l4.w));
+            ub = make_float4(fmaxf_std(ub.x, u4.x), fmaxf_std(ub.y, u4.y), fmaxf_std(ub.z, u4.z), fmaxf_std(ub.w, u4.w));
+        }
+    }
+    b.nb[no + p] = begin;
+    b.ne[no + p] = end;
+    b.npar[no + p] = parent;
+    b.nleft[no + p] = left;
+    b.nlb[no + p] = lb;
+    b.nub[no + p] = ub;
+    b.ndepth[no + p] = b.k_depth[no + id];
+    b.nsplit[no + p] = split;
+}
+
+// Internal-node AABBs of one level from the (already final) children one level below.
+// Fixed grid, grid-stride over the level; empty levels return at once.
+__global__ __launch_bounds__(256) void k_bvh_refit_level(bvh_bufs b, int level)
+{
+    const std::uint32_t c = blockIdx.y;
+    const std::uint32_t lo = b.level_off[c * (BVH_MAX_LEVELS + 1) + level];
+    const std::uint32_t hi = b.level_off[c * (BVH_MAX_LEVELS + 1) + level + 1];
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
+    for (std::uint32_t p = lo + blockIdx.x * blockDim.x + threadIdx.x; p < hi; p += gridDim.x * blockDim.x) {
+        const std::int32_t l = b.nleft[no + p];
+        if (l >= 0) {
+            const float4 a = b.nlb[no + l], bb = b.nlb[no + l + 1];
+            const float4 ua = b.nub[no + l], ubb = b.nub[no + l + 1];
+            b.nlb[no + p] = make_float4(fminf_std(a.x, bb.x), fminf_std(a.y, bb.y), fminf_std(a.z, bb.z), fminf_std(a.w, bb.w));
+            b.nub[no + p]
+                = make_float4(fmaxf_std(ua.x, ubb.x), fmaxf_std(ua.y, ubb.y), fmaxf_std(ua.z, ubb.z), fmaxf_std(ua.w, ubb.w));
+        }
+    }
+}
+
+// Reference node layout (include/cascade/detail/sim_data.hpp:193-207), 60 bytes.
+struct bvh_node_ref {
+    std::uint32_t begin, end;
+    std::int32_t parent, left, right;
+    float lb[4], ub[4];
+    std::uint32_t nn_level;
+    int split_idx;
+};
+static_assert(sizeof(bvh_node_ref) == 60, "bvh_node layout");
+
+__global__ __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t chunk, bvh_node_ref *out)
+{
+    const std::uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const std::uint32_t nn = b.n_nodes[chunk];
+    if (p >= nn) {
+        return;
+    }
+    const std::size_t no = static_cast<std::size_t>(chunk) * b.nn_max;
+    bvh_node_ref o;
+    o.begin = b.nb[no + p];
+    o.end = b.ne[no + p];
+    o.parent = b.npar[no + p];
+    o.left = b.nleft[no + p];
+    o.right = o.left < 0 ? -1 : o.left + 1;
+    const float4 lb = b.nlb[no + p], ub = b.nub[no + p];
+    o.lb[0] = lb.x;
+    o.lb[1] = lb.y;
+    o.lb[2] = lb.z;
+    o.lb[3] = lb.w;
+    o.ub[0] = ub.x;
+    o.ub[1] = ub.y;
+    o.ub[2] = ub.z;
+    o.ub[3] = ub.w;
+    o.nn_level = b.level_cnt[chunk * BVH_MAX_LEVELS + b.ndepth[no + p]];
+    o.split_idx = b.nsplit[no + p];
+    out[p] = o;
+}
+
+// ---------------------------------------------------------------------------
+// K6: broad phase. One lane per Morton-ordered particle, explicit DFS stack in LDS,
+// closed-interval overlap on 4 dimensions, pairs (orig_pidx < orig_i) with at least one
+// activity flag. Count pass -> exclusive scan -> write pass (deterministic layout: pairs
+// grouped by query particle in Morton order). Replaces src/sim_broad_phase.cpp:92-202.
+// Traffic: 36 B per visited node (L2-resident tree top, HBM for the deep levels) + 8 B
+// per pair written.
+// ---------------------------------------------------------------------------
+constexpr int BP_BLOCK = 64;
+constexpr int BP_STACK = 72; // depth <= 64 -> at most 65 pending entries
+
+struct bp_params {
+    std::uint32_t n;
+    std::uint32_t nn_max;
+    const float4 *slb, *sub;     // [C][n]
+    const std::uint32_t *vidx;   // [C][n]
+    const float4 *nlb, *nub;     // [C][nn_max]
+    const std::int32_t *nleft;
+    const std::uint32_t *nb, *ne;
+    const std::uint8_t *active;  // [n] bit0 coll_active, bit1 conj_active
+    std::uint32_t *count;        // [C][n] (count pass)
+    const std::uint64_t *offset; // [C * n + 1] exclusive scan over all chunks (write pass)
+    std::uint32_t *pairs;        // [total][2]
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(BP_BLOCK) void k_broad_phase(bp_params q)
+{
+    __shared__ std::int32_t stack[BP_STACK][BP_BLOCK];
+    const std::uint32_t c = blockIdx.y;
+    const std::uint32_t pidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= q.n) {
+        return;
+    }
+    const int tid = threadIdx.x;
+    const std::size_t po = static_cast<std::size_t>(c) * q.n;
+    const std::size_t no = static_cast<std::size_t>(c) * q.nn_max;
+    const std::uint32_t orig_pidx = q.vidx[po + pidx];
+    const bool act_p = q.active[orig_pidx] != 0;
+    const float4 plb = q.slb[po + pidx], pub = q.sub[po + pidx];
+    std::uint32_t cnt = 0;
+    std::uint64_t wpos = 0;
+    if constexpr (WRITE) {
+        wpos = q.offset[po + pidx];
+    }
+    int sp = 0;
+    stack[sp++][tid] = 0;
+    do {
+        const std::int32_t node = stack[--sp][tid];
+        const float4 nl = q.nlb[no + node], nu = q.nub[no + node];
+        const bool overlap = (pub.x >= nl.x && plb.x <= nu.x) && (pub.y >= nl.y && plb.y <= nu.y)
+                             && (pub.z >= nl.z && plb.z <= nu.z) && (pub.w >= nl.w && plb.w <= nu.w);
+        if (overlap) {
+            const std::int32_t left = q.nleft[no + node];
+            if (left == -1) {
+                const std::uint32_t b = q.nb[no + node], e = q.ne[no + node];
+                for (std::uint32_t i = b; i != e; ++i) {
+                    const std::uint32_t orig_i = q.vidx[po + i];
+                    if (orig_pidx >= orig_i) {
+                        continue;
+                    }
+                    if (act_p || q.active[orig_i] != 0) {
+                        if constexpr (WRITE) {
+                            q.pairs[(wpos + cnt) * 2u] = orig_pidx;
+                            q.pairs[(wpos + cnt) * 2u + 1u] = orig_i;
+                        }
+                        ++cnt;
+                    }
+                }
+            } else {
+                stack[sp++][tid] = left;
+                stack[sp++][tid] = left + 1;
+            }
+        }
+    } while (sp > 0);
+    if constexpr (!WRITE) {
+        q.count[po + pidx] = cnt;
+    }
+}
+
+} // namespace csc

@@ -1,0 +1,433 @@
+// cascade_amd/csrc/k_narrow.hpp
+//
+// K7: narrow phase. One lane per broad-phase pair; for every overlapping pair of substeps
+// inside the chunk the lane translates the x/y/z Taylor polynomials to a common origin,
+// builds the distance-square polynomial in registers and runs the fast exclusion check.
+// Only if that fails to exclude the interval does the lane enter the (rare, divergent)
+// root isolation + TOMS748 refinement. K8: dense output (Horner of the 6 coordinates).
+//
+// Replaces:
+//   src/sim_narrow_phase.cpp:495-1023  narrow_phase_parallel
+//   src/sim_narrow_phase.cpp:208-422   run_poly_root_finding (slow path in dev_math.hpp)
+//   src/sim_jit.cpp:64-113, 118-218    pta_cfunc / ssdiff3_cfunc (register versions here)
+//   src/sim_propagate.cpp:1386-1503    dense_propagate
+// Traffic per pair-interval: 2 x 504 B of Taylor coefficients (2 x 1008 B with conjunction
+// tracking survivors), 2 x 16 B substep times, 8 B pair; ~1.5 kFLOP. HBM/L2 bound.
+#pragma once
+
+#include "dev_math.hpp"
+
+namespace csc
+{
+
+struct coll_rec {
+    std::uint64_t i, j;
+    double time;
+};
+
+// include/cascade/sim.hpp:90-104
+struct conj_rec {
+    std::uint64_t i, j;
+    double time, dist;
+    double state_i[6], state_j[6];
+};
+static_assert(sizeof(conj_rec) == 128, "conjunction layout");
+
+struct np_params {
+    std::uint32_t n;       // particles
+    std::uint32_t nchunks; // chunks (after a possible STE shrink)
+    double ct, delta_t;    // delta_t after a possible STE shrink (src/sim_narrow_phase.cpp:560)
+    double init_hi, init_lo;
+    double conj_thresh2;
+    const double *state;          // [n][7] (sizes)
+    const std::uint8_t *active;   // [n] bit0 coll, bit1 conj
+    const std::uint64_t *tc_off;  // [n + 1]
+    const double *tcs;            // CSR rows of 7 * (P + 1)
+    const double *tcoords;        // CSR rows of 2
+    const std::uint32_t *pairs;   // [npairs][2]
+    const std::uint64_t *bp_off;  // [C * n0 + 1] broad-phase offsets (chunk c starts at bp_off[c * n0])
+    std::uint32_t n0;             // stride of bp_off per chunk (== n)
+    std::uint64_t npairs;
+    coll_rec *coll;
+    conj_rec *conj;
+    std::uint32_t coll_cap, conj_cap;
+    std::uint32_t *counters; // [0] n_coll, [1] n_conj, [2] warnings, [3] n slow-path entries
+};
+
+CSC_DEV dfl load_tcoord(const double *tcoords, std::uint64_t row)
+{
+    return dfl{tcoords[row * 2u], tcoords[row * 2u + 1u]};
+}
+
+// Substep range [first, last) covering a chunk (src/sim_propagate.cpp:275-287).
+CSC_DEV void substep_range(const double *tcoords, std::uint64_t off, std::uint32_t ns, dfl cb, dfl ce,
+                           std::uint32_t &first, std::uint32_t &last)
+{
+    // upper_bound(cb): first s with cb < tcoords[s]
+    std::uint32_t lo = 0, len = ns;
+    while (len > 0) {
+        const std::uint32_t half = len / 2, mid = lo + half;
+        if (!df_lt(cb, load_tcoord(tcoords, off + mid))) {
+            lo = mid + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    first = lo;
+    // lower_bound(ce) from first: first s with !(tcoords[s] < ce)
+    len = ns - lo;
+    while (len > 0) {
+        const std::uint32_t half = len / 2, mid = lo + half;
+        if (df_lt(load_tcoord(tcoords, off + mid), ce)) {
+            lo = mid + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    last = lo + (lo != ns ? 1u : 0u);
+}
+
+// out(x) = cf(x + a) in registers; same operation order as poly_translate_a (dev_math.hpp).
+template <int P>
+CSC_DEV void translate_a_regs(double *out, const double *cf, double a)
+{
+    double ap[P + 1];
+    ap[0] = 1.;
+    ap[1] = a;
+#pragma unroll
+    for (int i = 2; i <= P; ++i) {
+        if (i % 2 == 0) {
+            ap[i] = ap[i / 2] * ap[i / 2];
+        } else {
+            ap[i] = ap[i / 2 + 1] * ap[i / 2];
+        }
+    }
+    constexpr binom_tab bt = make_binom_tab();
+#pragma unroll
+    for (int i = 0; i <= P; ++i) {
+        double acc = 0;
+#pragma unroll
+        for (int k = i; k <= P; ++k) {
+            acc += (cf[k] * bt.v[k * BINOM_N + (k - i)]) * ap[k - i];
+        }
+        out[i] = acc;
+    }
+}
+
+// Coefficient i of p*p as written in src/sim_jit.cpp:175-202 (plain mul/add, no fma).
+template <int I>
+CSC_DEV double psquare(const double *p)
+{
+    if constexpr (I == 0) {
+        return p[0] * p[0];
+    } else if constexpr (I % 2 == 0) {
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; j <= I / 2 - 1; ++j) {
+            acc += p[I - j] * p[j];
+        }
+        return 2. * acc + p[I / 2] * p[I / 2];
+    } else {
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; j <= (I - 1) / 2; ++j) {
+            acc += p[I - j] * p[j];
+        }
+        return 2. * acc;
+    }
+}
+
+template <int P, int I>
+struct sq_all {
+    static CSC_DEV void run(double *out, const double *d)
+    {
+        out[I] = psquare<I>(d);
+        if constexpr (I < P) {
+            sq_all<P, I + 1>::run(out, d);
+        }
+    }
+};
+
+// Loads coordinate c of row `row`, translated by delta when delta != 0.
+template <int P>
+CSC_DEV void load_poly(double *out, const double *tcs, std::uint64_t row, int c, double delta)
+{
+    const double *src = tcs + row * static_cast<std::uint64_t>(7 * (P + 1)) + c * (P + 1);
+    double tmp[P + 1];
+#pragma unroll
+    for (int o = 0; o <= P; ++o) {
+        tmp[o] = src[o];
+    }
+    if (delta != 0.) {
+        translate_a_regs<P>(out, tmp, delta);
+    } else {
+#pragma unroll
+        for (int o = 0; o <= P; ++o) {
+            out[o] = tmp[o];
+        }
+    }
+}
+
+// Runtime-order copy of the same load (slow path; private memory).
+__device__ inline void load_poly_rt(double *out, const double *tcs, std::uint64_t row, int c, double delta, int P)
+{
+    const double *src = tcs + row * static_cast<std::uint64_t>(7 * (P + 1)) + c * (P + 1);
+    if (delta != 0.) {
+        double tmp[RF_MAX_ORDER + 1];
+        for (int o = 0; o <= P; ++o) {
+            tmp[o] = src[o];
+        }
+        poly_translate_a(out, tmp, delta, P);
+    } else {
+        for (int o = 0; o <= P; ++o) {
+            out[o] = src[o];
+        }
+    }
+}
+
+// Slow path: the fast exclusion check did not exclude a collision and/or a conjunction in
+// this interval. ss: the distance-square polynomial with its ORIGINAL constant term.
+template <int P>
+CSC_DEV_NOINLINE void np_slow_path(const np_params &q, const double *ss_in, bool do_coll, bool do_conj, double rsum2,
+                                   double rf_int, dfl lb_rf, std::uint32_t pi, std::uint32_t pj, std::uint64_t row_i,
+                                   std::uint64_t row_j, double delta_i, double delta_j)
+{
+    double ss[P + 1], roots[P + 1];
+    for (int o = 0; o <= P; ++o) {
+        ss[o] = ss_in[o];
+    }
+    int warn = 0;
+    atomicAdd(&q.counters[3], 1u);
+    if (do_coll) {
+        const double c0 = ss[0];
+        ss[0] = c0 - rsum2;
+        int nr = isolate_and_refine(ss, P, rf_int, -1, roots, P + 1, &warn);
+        if (nr < 0) {
+            nr = -1 - nr;
+        }
+        for (int k = 0; k < nr && k <= P; ++k) {
+            const double tcoll = df_add(lb_rf, df(roots[k])).hi;
+            if (!finite_d(tcoll)) {
+                warn |= 1;
+                continue;
+            }
+            const std::uint32_t slot = atomicAdd(&q.counters[0], 1u);
+            if (slot < q.coll_cap) {
+                q.coll[slot] = coll_rec{pi, pj, tcoll};
+            }
+        }
+        ss[0] = c0;
+    }
+    if (do_conj) {
+        double der[P + 1];
+        for (int i = 0; i < P; ++i) {
+            der[i] = (i + 1) * ss[i + 1];
+        }
+        der[P] = 0;
+        int nr = isolate_and_refine(der, P, rf_int, 1, roots, P + 1, &warn);
+        if (nr < 0) {
+            nr = -1 - nr;
+        }
+        for (int k = 0; k < nr && k <= P; ++k) {
+            const double conj_tm = df_add(df(0.), df(roots[k])).hi;
+            if (!finite_d(conj_tm)) {
+                warn |= 1;
+                continue;
+            }
+            const double conj_dist2 = poly_eval(ss, conj_tm, P);
+            if (!finite_d(conj_dist2)) {
+                warn |= 1;
+                continue;
+            }
+            if (conj_dist2 < q.conj_thresh2) {
+                conj_rec c;
+                c.i = pi;
+                c.j = pj;
+                const dfl init_time{q.init_hi, q.init_lo};
+                c.time = df_add(init_time, df_add(lb_rf, df(conj_tm))).hi;
+                c.dist = sqrt(dmax(conj_dist2, 0.));
+                double poly[P + 1];
+                for (int cc = 0; cc < 6; ++cc) {
+                    load_poly_rt(poly, q.tcs, row_i, cc, delta_i, P);
+                    c.state_i[cc] = poly_eval(poly, conj_tm, P);
+                    load_poly_rt(poly, q.tcs, row_j, cc, delta_j, P);
+                    c.state_j[cc] = poly_eval(poly, conj_tm, P);
+                }
+                const std::uint32_t slot = atomicAdd(&q.counters[1], 1u);
+                if (slot < q.conj_cap) {
+                    q.conj[slot] = c;
+                }
+            }
+        }
+    }
+    if (warn) {
+        atomicOr(&q.counters[2], static_cast<std::uint32_t>(warn));
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
+{
+    const std::uint64_t k = static_cast<std::uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= q.npairs) {
+        return;
+    }
+    // Chunk of this pair: last c with bp_off[c * n0] <= k.
+    std::uint32_t c = 0;
+    {
+        std::uint32_t lo = 0, hi = q.nchunks; // invariant: start(lo) <= k < start(hi) (start(nchunks) = npairs)
+        while (hi - lo > 1) {
+            const std::uint32_t mid = (lo + hi) / 2;
+            if (q.bp_off[static_cast<std::uint64_t>(mid) * q.n0] <= k) {
+                lo = mid;
+            } else {
+                hi = mid;
+            }
+        }
+        c = lo;
+    }
+    const std::uint32_t pi = q.pairs[k * 2u], pj = q.pairs[k * 2u + 1u];
+    const std::uint8_t ai = q.active[pi], aj = q.active[pj];
+    const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
+    const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
+    const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
+    const double rsum2 = (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
+
+    // get_chunk_begin_end (src/sim_basic.cpp:87-103)
+    const dfl chunk_begin = df(q.ct * static_cast<double>(c));
+    const dfl chunk_end = df((c == q.nchunks - 1u) ? q.delta_t : q.ct * static_cast<double>(c + 1u));
+
+    const std::uint64_t off_i = q.tc_off[pi], off_j = q.tc_off[pj];
+    const std::uint32_t ns_i = static_cast<std::uint32_t>(q.tc_off[pi + 1u] - off_i);
+    const std::uint32_t ns_j = static_cast<std::uint32_t>(q.tc_off[pj + 1u] - off_j);
+    std::uint32_t it_i, end_i, it_j, end_j;
+    substep_range(q.tcoords, off_i, ns_i, chunk_begin, chunk_end, it_i, end_i);
+    substep_range(q.tcoords, off_j, ns_j, chunk_begin, chunk_end, it_j, end_j);
+
+    while (it_i != end_i && it_j != end_j) {
+        const dfl ss_start_i = (it_i == 0u) ? df(0.) : load_tcoord(q.tcoords, off_i + it_i - 1u);
+        const dfl ss_start_j = (it_j == 0u) ? df(0.) : load_tcoord(q.tcoords, off_j + it_j - 1u);
+        const dfl tend_i = load_tcoord(q.tcoords, off_i + it_i);
+        const dfl tend_j = load_tcoord(q.tcoords, off_j + it_j);
+        const dfl lb_i = df_max(chunk_begin, ss_start_i), ub_i = df_min(chunk_end, tend_i);
+        const dfl lb_j = df_max(chunk_begin, ss_start_j), ub_j = df_min(chunk_end, tend_j);
+        const dfl lb_rf = df_max(lb_i, lb_j), ub_rf = df_min(ub_i, ub_j);
+        const double delta_i = df_sub(lb_rf, ss_start_i).hi;
+        const double delta_j = df_sub(lb_rf, ss_start_j).hi;
+        const double rf_int = df_sub(ub_rf, lb_rf).hi;
+
+        if (!finite_d(delta_i) || !finite_d(delta_j) || !finite_d(rf_int) || delta_i < 0 || delta_j < 0
+            || rf_int < 0) {
+            atomicOr(&q.counters[2], 16u);
+            break;
+        }
+
+        // Distance-square polynomial (ssdiff3, src/sim_jit.cpp:118-218), coordinate by coordinate.
+        double ss[P + 1];
+        {
+            double a[P + 1], b[P + 1], d[P + 1], sq[P + 1];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                load_poly<P>(a, q.tcs, off_i + it_i, cc, delta_i);
+                load_poly<P>(b, q.tcs, off_j + it_j, cc, delta_j);
+#pragma unroll
+                for (int o = 0; o <= P; ++o) {
+                    d[o] = a[o] - b[o];
+                }
+                sq_all<P, 0>::run(sq, d);
+#pragma unroll
+                for (int o = 0; o <= P; ++o) {
+                    ss[o] = (cc == 0) ? sq[o] : ss[o] + sq[o];
+                }
+            }
+        }
+
+        bool need_coll = false, need_conj = false, bail = false;
+        if (coll_act) {
+            const double c0 = ss[0];
+            ss[0] = c0 - rsum2;
+            need_coll = !fex_excluded<P>(ss, rf_int);
+            ss[0] = c0;
+        }
+        if (conj_act) {
+            const ivl d2 = iv_poly_eval<P>(ss, ivl{0., rf_int});
+            if (!finite_d(d2.lo) || !finite_d(d2.hi)) {
+                atomicOr(&q.counters[2], 32u);
+                bail = true;
+            } else if (d2.lo < q.conj_thresh2) {
+                double der[P + 1];
+#pragma unroll
+                for (int o = 0; o < P; ++o) {
+                    der[o] = (o + 1) * ss[o + 1];
+                }
+                der[P] = 0;
+                need_conj = !fex_excluded<P>(der, rf_int);
+            }
+        }
+        if (need_coll || (need_conj && !bail)) {
+            np_slow_path<P>(q, ss, need_coll, need_conj && !bail, rsum2, rf_int, lb_rf, pi, pj, off_i + it_i,
+                            off_j + it_j, delta_i, delta_j);
+        }
+        if (bail) {
+            break;
+        }
+
+        if (df_lt(tend_i, tend_j)) {
+            ++it_i;
+        } else if (df_lt(tend_j, tend_i)) {
+            ++it_j;
+        } else {
+            ++it_i;
+            ++it_j;
+        }
+    }
+}
+
+// K8: dense_propagate (src/sim_propagate.cpp:1401-1500). out: [n][6].
+template <int P>
+__global__ __launch_bounds__(256) void k_dense(std::uint32_t n, double t, const std::uint64_t *tc_off,
+                                               const double *tcs, const double *tcoords, double *out, int *err_flag)
+{
+    const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const std::uint64_t off = tc_off[i];
+    const std::uint32_t ns = static_cast<std::uint32_t>(tc_off[i + 1u] - off);
+    if (ns == 0u) {
+        atomicOr(err_flag, 1);
+        return;
+    }
+    const dfl dt = df(t);
+    // lower_bound(dt): first s with !(tcoords[s] < dt)
+    std::uint32_t lo = 0, len = ns;
+    while (len > 0) {
+        const std::uint32_t half = len / 2, mid = lo + half;
+        if (df_lt(load_tcoord(tcoords, off + mid), dt)) {
+            lo = mid + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    if (lo == ns) {
+        lo = ns - 1u;
+    }
+    const dfl ss_start = (lo == 0u) ? df(0.) : load_tcoord(tcoords, off + lo - 1u);
+    const double eval_tm = df_sub(dt, ss_start).hi;
+    const double *base = tcs + (off + lo) * static_cast<std::uint64_t>(7 * (P + 1));
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double *p = base + c * (P + 1);
+        double acc = p[P];
+#pragma unroll
+        for (int o = 1; o <= P; ++o) {
+            acc = p[P - o] + acc * eval_tm;
+        }
+        out[static_cast<std::uint64_t>(i) * 6u + c] = acc;
+    }
+}
+
+} // namespace csc

@@ -1,0 +1,474 @@
+// cascade_amd/csrc/k_propagate.hpp
+//
+// K1/K2: one-object-per-lane adaptive Taylor propagation over the superstep with the
+// per-chunk AABBs fused in (the coefficients never leave registers for that), and a
+// second "store" pass that writes the Taylor coefficients for dense output into an
+// exact-fit CSR layout once the substep counts are known.
+//
+// Replaces, for the built-in dynamics:
+//   src/sim_propagate.cpp:134-211   init_scalar_ta / init_batch_ta
+//   src/sim_propagate.cpp:650-877   batch_int_aabb integration loop + callback :710-755
+//   src/sim_propagate.cpp:927-1056  scalar_int_aabb (same per lane)
+//   src/sim_propagate.cpp:217-395   compute_particle_aabb (fused, pass 1)
+//   heyoka taylor_adaptive(_batch)<double>::propagate_for (EXTERNAL): Taylor
+//   coefficient recurrences, Jorba-Zou step size, terminal events, dfloat time.
+//
+// Layout. state [N][7] f64 (reference layout, sim.hpp:123). Pass 1 writes nsub[N],
+// status/event records, final_state [N][6], lbs/ubs [C][N][4] f32. Pass 2 writes
+// tcs [sum nsub][7][P+1] f64 and tcoords [sum nsub][2] f64 (hi, lo) at the CSR row
+// tc_off[i] + s: every particle-substep owns 1176 contiguous bytes (P = 20), which is
+// what the narrow phase wants (504 contiguous bytes for x, y, z).
+//
+// Roofline: pass 1 is FP64-VALU bound (~3.4 kFLOP per substep, no memory beyond 56 B
+// in / 84 B out per particle); pass 2 is HBM-write bound (1176 + 16 B per substep).
+#pragma once
+
+#include "dev_math.hpp"
+
+namespace csc
+{
+
+enum : int { DYN_KEPLER = 0 };
+
+enum : int {
+    ST_TIME_LIMIT = 0,
+    ST_STE = 1,
+    ST_NF = 2,
+    ST_FLAG_BAD_AABB = 0x100,   // non-finite AABB bound (src/sim_propagate.cpp:367-383)
+    ST_FLAG_BAD_TCOORD = 0x200, // non-finite time coordinate (:726-730)
+    ST_FLAG_MAX_SUBSTEPS = 0x400,
+    ST_FLAG_RF_WARN = 0x800,
+};
+
+struct prop_params {
+    const double *state; // [N][7]
+    std::uint32_t n;
+    double init_hi, init_lo;
+    double delta_t, ct;
+    std::uint32_t nchunks;
+    double conj_thresh;
+    double mu;
+    double rhofac;
+    // Terminal events (src/sim_basic.cpp:509-578): g = (kx x^2 + ky y^2) + kz z^2 - c0.
+    int has_exit;
+    double exit_c0;
+    int has_reentry;
+    double re_k[3];
+    double re_c0;
+    std::uint32_t max_substeps;
+    // pass 1
+    std::uint32_t *nsub;
+    std::int32_t *status;
+    std::uint32_t *ev_idx;
+    double *ev_time;
+    double *nf_last_t;
+    double *final_state; // [N][6]
+    float *lbs, *ubs;    // [C][N][4]
+    // pass 2
+    const std::uint64_t *tc_off; // [N + 1]
+    double *tcs;
+    double *tcoords;
+};
+
+// Coefficient n of a*b, ascending j, fma.
+template <int N>
+CSC_DEV double conv(const double *a, const double *b)
+{
+    double acc = 0;
+#pragma unroll
+    for (int j = 0; j <= N; ++j) {
+        acc = fma(a[j], b[N - j], acc);
+    }
+    return acc;
+}
+
+// Coefficient n of a*a by the symmetric half-sum.
+template <int N>
+CSC_DEV double conv_sq(const double *a)
+{
+    if constexpr (N == 0) {
+        return a[0] * a[0];
+    } else {
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; 2 * j < N; ++j) {
+            acc = fma(a[j], a[N - j], acc);
+        }
+        acc = acc + acc;
+        if constexpr (N % 2 == 0) {
+            acc = fma(a[N / 2], a[N / 2], acc);
+        }
+        return acc;
+    }
+}
+
+template <int P>
+struct tc_regs {
+    double x[P + 1], y[P + 1], z[P + 1], vx[P + 1], vy[P + 1], vz[P + 1], r[P + 1];
+};
+
+template <int P, int N>
+struct kepler_order {
+    static CSC_DEV void run(tc_regs<P> &t, double *u, double *w, double mu, double inv_u0, double inv_r0)
+    {
+        // u = x^2 + y^2 + z^2
+        u[N] = (conv_sq<N>(t.x) + conv_sq<N>(t.y)) + conv_sq<N>(t.z);
+        // w = u^(-3/2): w[n] = (1 / (n u0)) sum_{j<n} (n alpha - j (alpha + 1)) u[n-j] w[j]
+        if constexpr (N == 0) {
+            w[0] = 1. / (u[0] * sqrt(u[0]));
+        } else {
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double cf = 0.5 * static_cast<double>(j) - 1.5 * static_cast<double>(N);
+                acc = fma(cf * u[N - j], w[j], acc);
+            }
+            w[N] = (acc * inv_u0) * (1. / static_cast<double>(N));
+        }
+        const double ax = -mu * conv<N>(t.x, w);
+        const double ay = -mu * conv<N>(t.y, w);
+        const double az = -mu * conv<N>(t.z, w);
+        // r' = (x vx + y vy + z vz) / r
+        const double s = (conv<N>(t.x, t.vx) + conv<N>(t.y, t.vy)) + conv<N>(t.z, t.vz);
+        double acc = s;
+#pragma unroll
+        for (int j = 1; j <= N; ++j) {
+            const double qr = static_cast<double>(N - j + 1) * t.r[N - j + 1];
+            acc = fma(-t.r[j], qr, acc);
+        }
+        const double qn = acc * inv_r0;
+        constexpr double f = 1. / static_cast<double>(N + 1);
+        t.x[N + 1] = t.vx[N] * f;
+        t.y[N + 1] = t.vy[N] * f;
+        t.z[N + 1] = t.vz[N] * f;
+        t.vx[N + 1] = ax * f;
+        t.vy[N + 1] = ay * f;
+        t.vz[N + 1] = az * f;
+        t.r[N + 1] = qn * f;
+        if constexpr (N + 1 < P) {
+            kepler_order<P, N + 1>::run(t, u, w, mu, inv_u0, inv_r0);
+        }
+    }
+};
+
+// Normalised Taylor coefficients (orders 1..P) of the 7 state variables; order 0 must be
+// set by the caller. Kepler RHS src/sim_dynamics.cpp:36-41, r equation src/sim_basic.cpp:469.
+template <int P>
+CSC_DEV void compute_tcs_kepler(tc_regs<P> &t, double mu)
+{
+    double u[P], w[P];
+    // NOTE: u[0] is recomputed inside order 0; the reciprocals only need it.
+    const double u0 = (t.x[0] * t.x[0] + t.y[0] * t.y[0]) + t.z[0] * t.z[0];
+    const double inv_u0 = 1. / u0;
+    const double inv_r0 = 1. / t.r[0];
+    kepler_order<P, 0>::run(t, u, w, mu, inv_u0, inv_r0);
+}
+
+template <int P>
+CSC_DEV double horner_fma(const double *t, double h)
+{
+    double acc = t[P];
+#pragma unroll
+    for (int o = 1; o <= P; ++o) {
+        acc = fma(acc, h, t[P - o]);
+    }
+    return acc;
+}
+
+template <int P, int N>
+struct ev_poly_order {
+    static CSC_DEV void run(const tc_regs<P> &t, double *g, double kx, double ky, double kz)
+    {
+        g[N] = (kx * conv_sq<N>(t.x) + ky * conv_sq<N>(t.y)) + kz * conv_sq<N>(t.z);
+        if constexpr (N < P) {
+            ev_poly_order<P, N + 1>::run(t, g, kx, ky, kz);
+        }
+    }
+};
+
+// Slow path of terminal-event detection: full root isolation on g over [0, h).
+// Returns the earliest accepted root or a negative value if there is none.
+template <int P>
+CSC_DEV_NOINLINE double event_first_root(const double *g_in, double h, int direction, int *warn)
+{
+    double g[P + 1];
+    for (int i = 0; i <= P; ++i) {
+        g[i] = g_in[i];
+    }
+    double roots[P + 1];
+    int n = isolate_and_refine(g, P, h, direction, roots, P + 1, warn);
+    if (n < 0) {
+        n = -1 - n;
+    }
+    double best = -1.;
+    for (int k = 0; k < n && k <= P; ++k) {
+        if (best < 0. || roots[k] < best) {
+            best = roots[k];
+        }
+    }
+    return best;
+}
+
+template <int P, bool EVENTS, bool STORE>
+__global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
+{
+    const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= prm.n) {
+        return;
+    }
+
+    tc_regs<P> t;
+    const double *sp = prm.state + static_cast<std::size_t>(i) * 7u;
+    t.x[0] = sp[0];
+    t.y[0] = sp[1];
+    t.z[0] = sp[2];
+    t.vx[0] = sp[3];
+    t.vy[0] = sp[4];
+    t.vz[0] = sp[5];
+    const double p_radius = sp[6];
+    // src/sim_propagate.cpp:160
+    t.r[0] = sqrt(t.x[0] * t.x[0] + t.y[0] * t.y[0] + t.z[0] * t.z[0]);
+
+    const dfl init_time{prm.init_hi, prm.init_lo};
+    const dfl t_end = df_add(init_time, df(prm.delta_t));
+    dfl tm = init_time;
+    dfl tc_prev = df(0.); // end of the previous substep relative to init_time
+
+    int status = ST_TIME_LIMIT;
+    int flags = 0;
+    std::uint32_t ns = 0;
+    std::uint32_t ev_idx = 0;
+    double ev_time = 0., nf_last_t = 0.;
+
+    // Fused AABB state (pass 1): running box of the chunk being visited.
+    const std::uint32_t C = prm.nchunks;
+    std::uint32_t kc = 0;   // first chunk that may still overlap the coming substeps
+    std::uint32_t kbox = ~0u; // chunk whose box is being accumulated
+    float blo[4], bhi[4];
+    const float finf = __builtin_huge_valf();
+    const double infl = dmax(p_radius, prm.conj_thresh / 2);
+
+    if constexpr (!STORE) {
+        // Boxes of chunks that no substep reaches stay at +-inf (:238-244).
+        for (std::uint32_t k = 0; k < C; ++k) {
+            float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(k) * prm.n + i);
+            float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(k) * prm.n + i);
+            *plo = make_float4(finf, finf, finf, finf);
+            *phi = make_float4(-finf, -finf, -finf, -finf);
+        }
+    }
+    auto flush_box = [&]() {
+        if constexpr (!STORE) {
+            if (kbox != ~0u) {
+                float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(kbox) * prm.n + i);
+                float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(kbox) * prm.n + i);
+                *plo = make_float4(blo[0], blo[1], blo[2], blo[3]);
+                *phi = make_float4(bhi[0], bhi[1], bhi[2], bhi[3]);
+            }
+        }
+    };
+
+    std::size_t row = 0;
+    if constexpr (STORE) {
+        row = prm.tc_off[i];
+    }
+
+    while (true) {
+        const dfl rem = df_sub(t_end, tm);
+        const double max_dt = rem.hi > 0. ? rem.hi : 0.;
+
+        compute_tcs_kepler<P>(t, prm.mu);
+
+        // Jorba-Zou step size (heyoka, EXTERNAL).
+        double m0 = 0, mo = 0, mom1 = 0;
+        bool bad = false;
+        {
+            const double *arrs[7] = {t.x, t.y, t.z, t.vx, t.vy, t.vz, t.r};
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const double a0 = fabs(arrs[c][0]), ao = fabs(arrs[c][P]), aom1 = fabs(arrs[c][P - 1]);
+                bad = bad || !finite_d(a0) || !finite_d(ao) || !finite_d(aom1);
+                m0 = dmax(m0, a0);
+                mo = dmax(mo, ao);
+                mom1 = dmax(mom1, aom1);
+            }
+        }
+        if (bad) {
+            status = ST_NF;
+            nf_last_t = tc_prev.hi;
+            break;
+        }
+        const double num = m0 < 1. ? 1. : m0;
+        const double rho_o = det_pow(num / mo, 1. / static_cast<double>(P));
+        const double rho_om1 = det_pow(num / mom1, 1. / static_cast<double>(P - 1));
+        double h = dmin(rho_o, rho_om1) * prm.rhofac;
+        bool tlimit = false;
+        if (!(h < max_dt)) {
+            if (h != h) {
+                status = ST_NF;
+                nf_last_t = tc_prev.hi;
+                break;
+            }
+            h = max_dt;
+            tlimit = true;
+        }
+
+        // Terminal events in [0, h).
+        bool ev_found = false;
+        if constexpr (EVENTS) {
+            if (h > 0.) {
+                double ev_t = 0.;
+                std::uint32_t idx = 0;
+                if (prm.has_exit) {
+                    double g[P + 1];
+                    ev_poly_order<P, 0>::run(t, g, 1., 1., 1.);
+                    g[0] -= prm.exit_c0;
+                    if (!fex_excluded<P>(g, h)) {
+                        const double rt = event_first_root<P>(g, h, 1, &flags);
+                        if (rt >= 0.) {
+                            ev_found = true;
+                            ev_t = rt;
+                            ev_idx = 0;
+                        }
+                    }
+                    idx = 1;
+                }
+                if (prm.has_reentry) {
+                    double g[P + 1];
+                    ev_poly_order<P, 0>::run(t, g, prm.re_k[0], prm.re_k[1], prm.re_k[2]);
+                    g[0] -= prm.re_c0;
+                    if (!fex_excluded<P>(g, h)) {
+                        const double rt = event_first_root<P>(g, h, -1, &flags);
+                        if (rt >= 0. && (!ev_found || rt < ev_t)) {
+                            ev_found = true;
+                            ev_t = rt;
+                            ev_idx = idx;
+                        }
+                    }
+                }
+                if (ev_found) {
+                    h = ev_t;
+                    tlimit = false;
+                }
+            }
+        }
+
+        // Advance state and time.
+        const double nx = horner_fma<P>(t.x, h), ny = horner_fma<P>(t.y, h), nz = horner_fma<P>(t.z, h);
+        const double nvx = horner_fma<P>(t.vx, h), nvy = horner_fma<P>(t.vy, h), nvz = horner_fma<P>(t.vz, h);
+        const double nr = horner_fma<P>(t.r, h);
+        const dfl nt = df_add(tm, df(h));
+        const bool fin = finite_d(nx) && finite_d(ny) && finite_d(nz) && finite_d(nvx) && finite_d(nvy)
+                         && finite_d(nvz) && finite_d(nr) && df_finite(nt);
+        if (!fin) {
+            status = ST_NF;
+            nf_last_t = tc_prev.hi;
+            break;
+        }
+        tm = nt;
+
+        // The propagate callback (:710-755): record the substep unless h == 0.
+        if (h != 0.) {
+            const dfl tc = df_sub(tm, init_time);
+            if (!df_finite(tc)) {
+                flags |= ST_FLAG_BAD_TCOORD;
+            }
+            if constexpr (STORE) {
+                double *dst = prm.tcs + (row + ns) * static_cast<std::size_t>(7 * (P + 1));
+                const double *arrs[7] = {t.x, t.y, t.z, t.vx, t.vy, t.vz, t.r};
+#pragma unroll
+                for (int c = 0; c < 7; ++c) {
+#pragma unroll
+                    for (int o = 0; o <= P; ++o) {
+                        dst[c * (P + 1) + o] = arrs[c][o];
+                    }
+                }
+                prm.tcoords[(row + ns) * 2u] = tc.hi;
+                prm.tcoords[(row + ns) * 2u + 1u] = tc.lo;
+            } else {
+                // Fused compute_particle_aabb (:217-395): chunks k with cb_k < tc and ce_k > tc_prev.
+                while (kc < C) {
+                    const double ce = (kc == C - 1u) ? prm.delta_t : prm.ct * static_cast<double>(kc + 1u);
+                    if (df_lt(tc_prev, df(ce))) {
+                        break;
+                    }
+                    ++kc;
+                }
+                for (std::uint32_t k = kc; k < C; ++k) {
+                    const double cb = prm.ct * static_cast<double>(k);
+                    if (!df_lt(df(cb), tc)) {
+                        break;
+                    }
+                    const double ce = (k == C - 1u) ? prm.delta_t : prm.ct * static_cast<double>(k + 1u);
+                    const dfl ev_lb = df_max(df(cb), tc_prev);
+                    const dfl ev_ub = df_min(df(ce), tc);
+                    const ivl hint{df_sub(ev_lb, tc_prev).hi, df_sub(ev_ub, tc_prev).hi};
+                    if (k != kbox) {
+                        flush_box();
+                        kbox = k;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            blo[q] = finf;
+                            bhi[q] = -finf;
+                        }
+                    }
+                    const double *arrs[4] = {t.x, t.y, t.z, t.r};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ivl v = iv_poly_eval<P>(arrs[q], hint);
+                        v.lo -= infl;
+                        v.hi += infl;
+                        const float fl = nextafterf(static_cast<float>(v.lo), -finf);
+                        const float fu = nextafterf(static_cast<float>(v.hi), finf);
+                        if (!(fabsf(fl) <= FLT_MAX) || !(fabsf(fu) <= FLT_MAX)) {
+                            flags |= ST_FLAG_BAD_AABB;
+                        }
+                        blo[q] = fminf_std(blo[q], fl);
+                        bhi[q] = fmaxf_std(bhi[q], fu);
+                    }
+                }
+            }
+            tc_prev = tc;
+            ++ns;
+        }
+
+        t.x[0] = nx;
+        t.y[0] = ny;
+        t.z[0] = nz;
+        t.vx[0] = nvx;
+        t.vy[0] = nvy;
+        t.vz[0] = nvz;
+        t.r[0] = nr;
+
+        if (ev_found) {
+            status = ST_STE;
+            ev_time = df_sub(tm, init_time).hi;
+            break;
+        }
+        if (tlimit) {
+            break;
+        }
+        if (ns >= prm.max_substeps) {
+            flags |= ST_FLAG_MAX_SUBSTEPS;
+            break;
+        }
+    }
+
+    if constexpr (!STORE) {
+        flush_box();
+        prm.nsub[i] = ns;
+        prm.status[i] = status | flags;
+        prm.ev_idx[i] = ev_idx;
+        prm.ev_time[i] = ev_time;
+        prm.nf_last_t[i] = nf_last_t;
+        double *fs = prm.final_state + static_cast<std::size_t>(i) * 6u;
+        fs[0] = t.x[0];
+        fs[1] = t.y[0];
+        fs[2] = t.z[0];
+        fs[3] = t.vx[0];
+        fs[4] = t.vy[0];
+        fs[5] = t.vz[0];
+    }
+}
+
+} // namespace csc

@@ -1,0 +1,292 @@
+// cascade_amd/csrc/k_scan_sort.hpp
+//
+// Device-wide primitives used by several stages: exclusive prefix sums and a stable
+// LSD radix sort of (u64 key, u32 value) pairs, segmented over chunks (blockIdx.y).
+//
+// K4 replaces the indirect sort of src/sim_propagate.cpp:483-486 (oneTBB parallel_sort,
+// unstable) with a STABLE sort: ties keep ascending original index, which is what vidx's
+// iota initialisation (:1103-1116) yields under any stable algorithm. Tie order cannot
+// change the BVH topology (equal codes share a leaf) nor the broad-phase pair set.
+//
+// Radix pass = histogram kernel + scan kernel + scatter kernel, 8 bits per pass. Ranking
+// inside a tile is wave-cooperative: 64 consecutive keys per wave instruction, peers with
+// the same digit found with 8 ballots, per-wave digit counters in LDS. Traffic per key per
+// pass: 12 B read (histogram re-reads 8 B) + 12 B written; HBM bound.
+#pragma once
+
+#include "dev_math.hpp"
+
+namespace csc
+{
+
+// ---------------------------------------------------------------------------
+// Segmented exclusive scan of u32 -> u64 / u32, three kernels.
+// ---------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ inline std::uint64_t block_exclusive_scan_u64(std::uint64_t v, std::uint64_t *total, std::uint64_t *lds)
+{
+    // lds: SCAN_BLOCK / 64 + 1 entries.
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    std::uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const std::uint64_t o = __shfl_up(incl, d);
+        if (lane >= d) {
+            incl += o;
+        }
+    }
+    if (lane == 63) {
+        lds[wid] = incl;
+    }
+    __syncthreads();
+    std::uint64_t base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) {
+        const std::uint64_t s = lds[w];
+        if (w < wid) {
+            base += s;
+        }
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// Segmented: blockIdx.y = segment, every segment has n inputs. block_sums: [nseg][nb].
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block_sums(const std::uint32_t *in, std::uint64_t n,
+                                                                std::uint64_t *block_sums)
+{
+    __shared__ std::uint64_t lds[SCAN_BLOCK / 64 + 1];
+    in += static_cast<std::uint64_t>(blockIdx.y) * n;
+    const std::uint64_t base = static_cast<std::uint64_t>(blockIdx.x) * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    std::uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) {
+            s += in[base + k];
+        }
+    }
+    std::uint64_t tot;
+    block_exclusive_scan_u64(s, &tot, lds);
+    if (threadIdx.x == 0) {
+        block_sums[static_cast<std::uint64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// One block per segment: exclusive scan of the segment's block sums in place; totals[seg].
+__global__ __launch_bounds__(1024) void k_scan_sums(std::uint64_t *block_sums, std::uint64_t nb, std::uint64_t *totals)
+{
+    __shared__ std::uint64_t lds[1024 / 64 + 1];
+    __shared__ std::uint64_t carry_s;
+    block_sums += static_cast<std::uint64_t>(blockIdx.x) * nb;
+    if (threadIdx.x == 0) {
+        carry_s = 0;
+    }
+    __syncthreads();
+    for (std::uint64_t start = 0; start < nb; start += 1024) {
+        const std::uint64_t idx = start + threadIdx.x;
+        const std::uint64_t v = idx < nb ? block_sums[idx] : 0;
+        std::uint64_t tot;
+        const std::uint64_t ex = block_exclusive_scan_u64(v, &tot, lds);
+        const std::uint64_t carry = carry_s;
+        if (idx < nb) {
+            block_sums[idx] = carry + ex;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry_s = carry + tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[blockIdx.x] = carry_s;
+    }
+}
+
+// out: [nseg][n + 1] u64 (or u32 when OUT32), out[seg][n] = total of the segment.
+template <typename OutT>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const std::uint32_t *in, std::uint64_t n,
+                                                           const std::uint64_t *block_sums, OutT *out,
+                                                           const std::uint64_t *totals)
+{
+    __shared__ std::uint64_t lds[SCAN_BLOCK / 64 + 1];
+    in += static_cast<std::uint64_t>(blockIdx.y) * n;
+    out += static_cast<std::uint64_t>(blockIdx.y) * (n + 1u);
+    const std::uint64_t base = static_cast<std::uint64_t>(blockIdx.x) * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    std::uint32_t v[SCAN_ITEMS];
+    std::uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        s += v[k];
+    }
+    std::uint64_t tot;
+    std::uint64_t ex = block_exclusive_scan_u64(s, &tot, lds)
+                       + block_sums[static_cast<std::uint64_t>(blockIdx.y) * gridDim.x + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) {
+            out[base + k] = static_cast<OutT>(ex);
+        }
+        ex += v[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n] = static_cast<OutT>(totals[blockIdx.y]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Radix sort.
+// ---------------------------------------------------------------------------
+constexpr int RS_BLOCK = 256;
+constexpr int RS_WAVES = RS_BLOCK / 64;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per block
+constexpr int RS_BINS = 256;
+
+// block_hist layout: [chunk][bin][nblocks] (so that one linear exclusive scan per chunk
+// gives the global offset of (bin, block)).
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const std::uint64_t *keys, std::uint32_t n, int shift,
+                                                      std::uint32_t *block_hist, std::uint32_t nblocks)
+{
+    __shared__ std::uint32_t h[RS_BINS];
+    const std::uint32_t chunk = blockIdx.y;
+    keys += static_cast<std::size_t>(chunk) * n;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const std::uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const std::uint32_t idx = base + k * RS_BLOCK + threadIdx.x;
+        if (idx < n) {
+            const std::uint32_t d = static_cast<std::uint32_t>(keys[idx] >> shift) & 0xffu;
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    block_hist[(static_cast<std::size_t>(chunk) * RS_BINS + threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// One block per chunk: exclusive scan over RS_BINS * nblocks counters, in place.
+__global__ __launch_bounds__(1024) void k_rs_scan(std::uint32_t *block_hist, std::uint32_t nblocks)
+{
+    __shared__ std::uint64_t lds[1024 / 64 + 1];
+    __shared__ std::uint32_t carry_s;
+    const std::uint32_t chunk = blockIdx.x;
+    std::uint32_t *h = block_hist + static_cast<std::size_t>(chunk) * RS_BINS * nblocks;
+    const std::uint32_t tot_n = RS_BINS * nblocks;
+    if (threadIdx.x == 0) {
+        carry_s = 0;
+    }
+    __syncthreads();
+    constexpr int PER = 8;
+    for (std::uint32_t start = 0; start < tot_n; start += 1024 * PER) {
+        const std::uint32_t b = start + threadIdx.x * PER;
+        std::uint32_t v[PER];
+        std::uint64_t s = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            v[k] = (b + k < tot_n) ? h[b + k] : 0u;
+            s += v[k];
+        }
+        std::uint64_t tot;
+        std::uint32_t ex = static_cast<std::uint32_t>(block_exclusive_scan_u64(s, &tot, lds)) + carry_s;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (b + k < tot_n) {
+                h[b + k] = ex;
+            }
+            ex += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry_s += static_cast<std::uint32_t>(tot);
+        }
+        __syncthreads();
+    }
+}
+
+// vals_in == nullptr means "iota" (first pass of an index sort).
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const std::uint64_t *keys_in, const std::uint32_t *vals_in,
+                                                         std::uint64_t *keys_out, std::uint32_t *vals_out,
+                                                         std::uint32_t n, int shift, const std::uint32_t *block_hist,
+                                                         std::uint32_t nblocks)
+{
+    __shared__ std::uint32_t cnt[RS_WAVES][RS_BINS];
+    const std::uint32_t chunk = blockIdx.y;
+    const std::size_t coff = static_cast<std::size_t>(chunk) * n;
+    keys_in += coff;
+    keys_out += coff;
+    if (vals_in) {
+        vals_in += coff;
+    }
+    vals_out += coff;
+    const std::uint32_t *goff = block_hist + static_cast<std::size_t>(chunk) * RS_BINS * nblocks;
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < RS_WAVES * RS_BINS; k += RS_BLOCK) {
+        (&cnt[0][0])[k] = 0;
+    }
+    __syncthreads();
+
+    const std::uint32_t wbase = blockIdx.x * RS_TILE + wid * (RS_ITEMS * 64);
+    std::uint64_t key[RS_ITEMS];
+    std::uint32_t rank[RS_ITEMS];
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const std::uint32_t idx = wbase + it * 64 + lane;
+        const bool valid = idx < n;
+        key[it] = valid ? keys_in[idx] : ~0ull;
+        const std::uint32_t d = static_cast<std::uint32_t>(key[it] >> shift) & 0xffu;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        // All peers read the running count, then the leader bumps it.
+        std::uint32_t pre = 0;
+        if (valid) {
+            pre = cnt[wid][d];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0ull) {
+            cnt[wid][d] = pre + static_cast<std::uint32_t>(__popcll(peers));
+        }
+        __builtin_amdgcn_wave_barrier();
+        rank[it] = pre + static_cast<std::uint32_t>(__popcll(peers & lt_mask));
+    }
+    __syncthreads();
+    // Turn the per-wave counts into per-wave bases: global offset of (digit, block) plus the
+    // counts of the preceding waves of this block.
+    {
+        const int d = threadIdx.x; // RS_BLOCK == RS_BINS
+        std::uint32_t run = goff[static_cast<std::size_t>(d) * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const std::uint32_t c = cnt[w][d];
+            cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const std::uint32_t idx = wbase + it * 64 + lane;
+        if (idx < n) {
+            const std::uint32_t d = static_cast<std::uint32_t>(key[it] >> shift) & 0xffu;
+            const std::uint32_t pos = cnt[wid][d] + rank[it];
+            keys_out[pos] = key[it];
+            vals_out[pos] = vals_in ? vals_in[idx] : idx;
+        }
+    }
+}
+
+} // namespace csc

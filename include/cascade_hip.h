@@ -1,0 +1,238 @@
+/* include/cascade_hip.h
+ *
+ * C ABI of libcascade_hip.so: the MI355X (gfx950) kernels behind cascade::sim::step().
+ *
+ * The reference (esa/cascade) has no FFI boundary around step(): its stages are private
+ * member functions of cascade::sim working on sim::sim_data. This header is the boundary
+ * this build introduces between the C++ host orchestration (include/cascade/sim.hpp,
+ * cascade_amd/csrc/sim.cpp) and the HIP kernels. Every entry point cites the reference
+ * code it replaces (paths relative to the esa/cascade tree). Conventions:
+ *   - plain pointers and sizes only; pointers named d_* are DEVICE pointers;
+ *   - every function returns 0 on success or a negative csc_status; nothing throws;
+ *   - launches are asynchronous on the context's stream unless the function has host
+ *     outputs (documented per function), in which case it synchronises that stream;
+ *   - scratch memory lives in the context (grow-only, like the reference's
+ *     resize_if_needed, src/sim_propagate.cpp:561-569); callers own inputs and outputs;
+ *   - one host thread per context; a context is bound to one device.
+ * There is no CPU fallback: without a HIP device csc_ctx_create fails.
+ */
+#ifndef CASCADE_HIP_H
+#define CASCADE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct csc_ctx csc_ctx;
+
+typedef enum csc_status {
+    CSC_OK = 0,
+    CSC_ERR_HIP = -1,            /* a HIP runtime call failed (see csc_last_error) */
+    CSC_ERR_INVALID = -2,        /* invalid argument */
+    CSC_ERR_UNSUPPORTED = -3,    /* e.g. Taylor order other than 20, unknown dynamics */
+    CSC_ERR_NONFINITE_AABB = -4, /* src/sim_propagate.cpp:367-383, :453-456 */
+    CSC_ERR_NONFINITE_TIME = -5, /* src/sim_propagate.cpp:726-730 */
+    CSC_ERR_MAX_SUBSTEPS = -6,   /* safety cap on substeps per particle per superstep */
+    CSC_ERR_NO_SUBSTEPS = -7,    /* src/sim_propagate.cpp:1419-1440 */
+    CSC_ERR_OVERFLOW = -8        /* an output buffer was too small (sizes returned) */
+} csc_status;
+
+/* Built-in dynamics (replace the heyoka expression vector of kw::dyn, sim.hpp:213-222). */
+enum { CSC_DYN_KEPLER = 0 }; /* src/sim_dynamics.cpp:25-42 */
+
+/* Integrator + event configuration of one superstep. Replaces what sim::finalise_ctor bakes
+ * into the heyoka integrators (src/sim_basic.cpp:461-578). */
+typedef struct csc_prop_cfg {
+    int32_t dyn_kind;      /* CSC_DYN_* */
+    uint32_t order;        /* Taylor order p (20 for tol = DBL_EPSILON) */
+    double mu;             /* gravitational parameter */
+    double rhofac;         /* exp(-0.7 / (p - 1)) / e^2 (step-size safety factor) */
+    double init_time_hi;   /* double-length simulation time at the superstep start */
+    double init_time_lo;
+    double delta_t;        /* superstep size = ct * nchunks (src/sim_propagate.cpp:538) */
+    double ct;             /* collisional timestep */
+    uint32_t nchunks;      /* n_par_ct */
+    uint32_t max_substeps; /* safety cap (0 = default 1 << 20) */
+    double conj_thresh;    /* AABB inflation uses max(size, conj_thresh / 2) (:354-359) */
+    /* terminal events g = (kx x^2 + ky y^2) + kz z^2 - c0 (src/sim_basic.cpp:509-533) */
+    int32_t has_exit;      /* event index 0 when present, direction + */
+    double exit_c0;        /* R_exit^2 */
+    int32_t has_reentry;   /* event index has_exit, direction - */
+    double reentry_k[3];   /* {1,1,1} for a sphere; {(bc)^2, (ac)^2, (ab)^2} for an ellipsoid */
+    double reentry_c0;     /* R^2 or (abc)^2 */
+} csc_prop_cfg;
+
+/* Per-particle status written by csc_propagate: low byte 0 time limit / 1 stopping terminal
+ * event / 2 non-finite state; flag bits as below. */
+enum {
+    CSC_ST_TIME_LIMIT = 0,
+    CSC_ST_STE = 1,
+    CSC_ST_NF = 2,
+    CSC_ST_FLAG_BAD_AABB = 0x100,
+    CSC_ST_FLAG_BAD_TCOORD = 0x200,
+    CSC_ST_FLAG_MAX_SUBSTEPS = 0x400
+};
+
+/* Summary of a propagation pass (host struct filled by csc_propagate_summary). */
+typedef struct csc_prop_summary {
+    uint32_t flags;        /* OR of all per-particle flag bits */
+    uint32_t n_nf;         /* particles with a non-finite state */
+    uint32_t nf_idx;       /* earliest (lowest index on ties), src/sim_propagate.cpp:1127-1135 */
+    double nf_time;
+    uint32_t n_ste;        /* particles stopped by a terminal event */
+    uint32_t ste_idx;      /* earliest (lowest index on ties), :1148-1153 */
+    uint32_t ste_ev_idx;
+    double ste_time;
+    uint64_t total_substeps;
+} csc_prop_summary;
+
+/* Collision record (the tuple of sim_data::coll_vec, sim_data.hpp:304) and conjunction record
+ * (sim::conjunction, include/cascade/sim.hpp:90-104; numpy dtype cascade.py/core.cpp:81). */
+typedef struct csc_collision {
+    uint64_t i, j;
+    double time; /* relative to the superstep start */
+} csc_collision;
+
+typedef struct csc_conjunction {
+    uint64_t i, j;
+    double time; /* absolute */
+    double dist;
+    double state_i[6], state_j[6];
+} csc_conjunction;
+
+/* bvh_node of the reference (include/cascade/detail/sim_data.hpp:193-207), 60 bytes. */
+typedef struct csc_bvh_node {
+    uint32_t begin, end;
+    int32_t parent, left, right;
+    float lb[4], ub[4];
+    uint32_t nn_level;
+    int32_t split_idx;
+} csc_bvh_node;
+
+/* ---- context, memory, timing ------------------------------------------------------- */
+int csc_ctx_create(int device, csc_ctx **out);
+void csc_ctx_destroy(csc_ctx *ctx);
+const char *csc_last_error(csc_ctx *ctx); /* ctx may be NULL: last creation error */
+int csc_malloc(csc_ctx *ctx, size_t bytes, void **d_ptr);
+int csc_free(csc_ctx *ctx, void *d_ptr);
+int csc_memcpy_h2d(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes); /* synchronous */
+int csc_memcpy_d2h(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes); /* synchronous */
+int csc_memcpy_d2d(csc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); /* async */
+int csc_memset(csc_ctx *ctx, void *d_dst, int value, size_t bytes);           /* async */
+int csc_sync(csc_ctx *ctx);
+/* HIP-event stopwatch on the context's stream: ms between begin and end. */
+int csc_timer_begin(csc_ctx *ctx);
+int csc_timer_end(csc_ctx *ctx, float *ms);
+
+/* ---- K1/K2: propagation + AABBs -----------------------------------------------------
+ * Replaces batch_int_aabb / scalar_int_aabb (src/sim_propagate.cpp:650-1098), the
+ * propagate callback (:710-755), compute_particle_aabb (:217-395) and heyoka's
+ * propagate_for (EXTERNAL). d_state [n][7] f64. Outputs: d_nsub [n] u32 (substeps taken),
+ * d_status [n] i32, d_ev_idx [n] u32, d_ev_time [n] f64 (terminal event time relative to
+ * the superstep start), d_nf_last_t [n] f64, d_final_state [n][6] f64,
+ * d_lbs / d_ubs [nchunks][n][4] f32. Asynchronous. */
+int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
+                  int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
+                  double *d_final_state, float *d_lbs, float *d_ubs);
+
+/* Reductions over the per-particle records (earliest nf state / terminal event, flags,
+ * total substeps): src/sim_propagate.cpp:1127-1153. Synchronises; fills *out on the host. */
+int csc_propagate_summary(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, const int32_t *d_status,
+                          const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,
+                          csc_prop_summary *out);
+
+/* Exclusive prefix sum u32 -> u64 with d_out[n] = total. Asynchronous. */
+int csc_exclusive_scan(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out);
+
+/* Second pass: stores the Taylor coefficients (sim_data::step_data, sim_data.hpp:144-159)
+ * in CSR form: row d_tc_off[i] + s holds tcs [7][p + 1] f64 and tcoords {hi, lo}. d_tc_off
+ * [n + 1] is the exclusive scan of d_nsub. Asynchronous. */
+int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state,
+                        const uint64_t *d_tc_off, double *d_tcs, double *d_tcoords);
+
+/* Per-chunk global AABB (src/sim_propagate.cpp:883-920, src/detail/atomic_utils.cpp:20-55;
+ * exact like verify_global_aabbs :1348-1380). d_glb / d_gub [nchunks][4] f32 (upper bound NOT
+ * yet bumped). Asynchronous. */
+int csc_global_aabb(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs, float *d_glb,
+                    float *d_gub);
+
+/* ---- K3/K4: Morton codes, sort, gather -------------------------------------------------
+ * csc_morton_encode: src/sim_propagate.cpp:440-479 (+ disc_single_coord :94-124 and
+ * MortonNDLutEncoder<4,16,8>, src/detail/mortonND_LUT.h:166-323). The ulp bump of the global
+ * upper bound (:448-449) is applied internally. d_codes [nchunks][n] u64. Asynchronous; a
+ * non-finite global box is reported by the next synchronising call as
+ * CSC_ERR_NONFINITE_AABB through csc_check_flags. */
+int csc_morton_encode(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs,
+                      const float *d_glb, const float *d_gub, uint64_t *d_codes);
+int csc_check_flags(csc_ctx *ctx); /* synchronises; returns and clears the pending error */
+
+/* Stable indirect sort by code (src/sim_propagate.cpp:483-486; STABLE where oneTBB's
+ * parallel_sort leaves ties unspecified) and gather (:493-504). d_vidx [nchunks][n] u32,
+ * d_srt_codes [nchunks][n] u64, d_srt_lbs / d_srt_ubs [nchunks][n][4] f32. Asynchronous. */
+int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_codes, const float *d_lbs,
+                    const float *d_ubs, uint32_t *d_vidx, uint64_t *d_srt_codes, float *d_srt_lbs,
+                    float *d_srt_ubs);
+
+/* ---- K5: BVH ---------------------------------------------------------------------------
+ * construct_bvh_trees_parallel (src/sim_bvh.cpp:89-496). The trees live in the context.
+ * Asynchronous. csc_bvh_export copies the tree of one chunk in the reference's node layout
+ * (canonical level order) to d_nodes (capacity cap nodes) and returns the node count in
+ * *n_nodes (synchronises). */
+int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_srt_codes, const float *d_srt_lbs,
+                  const float *d_srt_ubs);
+int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t cap, uint64_t *n_nodes);
+
+/* ---- K6: broad phase -------------------------------------------------------------------
+ * broad_phase_parallel (src/sim_broad_phase.cpp:44-218) on the trees of the last
+ * csc_bvh_build. d_active [n] u8: bit 0 coll_active, bit 1 conj_active
+ * (src/sim_propagate.cpp:639-647). The pair list lives in the context: pairs of chunk c are
+ * rows [off[c], off[c + 1]) of a [total][2] u32 array, grouped by query particle in Morton
+ * order. Synchronises (the total is needed to size the list); *n_pairs = total over chunks. */
+int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                    const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs);
+/* Copies the pairs of one chunk to the host (for parity checks). *count = number of pairs;
+ * at most cap pairs are written. Synchronises. */
+int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t cap, uint64_t *count);
+
+/* ---- K7: narrow phase ------------------------------------------------------------------
+ * narrow_phase_parallel (src/sim_narrow_phase.cpp:495-1023) over the pair list of the last
+ * csc_broad_phase. nchunks / delta_t are the values AFTER a possible terminal-event shrink
+ * (:560). Results live in the context; synchronises; counts returned. */
+int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                     double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                     const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs, const double *d_tcoords,
+                     uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags);
+/* Same, on a caller-provided pair list d_pairs [npairs][2] with per-chunk row offsets
+ * pair_off [nchunks + 1] (host array). For parity checks on injected pairs. */
+int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                           double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                           const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs,
+                           const double *d_tcoords, const uint32_t *d_pairs, const uint64_t *pair_off,
+                           uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags);
+int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,
+                         uint64_t conj_cap); /* host copies, sorted by (time, i, j) */
+
+/* ---- K8: dense output ------------------------------------------------------------------
+ * dense_propagate (src/sim_propagate.cpp:1386-1503): state of every particle at time t
+ * (relative to the superstep start) into d_out [n][6]. Asynchronous; a particle without
+ * substeps raises CSC_ERR_NO_SUBSTEPS through csc_check_flags. */
+int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, const uint64_t *d_tc_off,
+                        const double *d_tcs, const double *d_tcoords, double *d_out);
+
+/* state[:, 0:6] <- final_state (copy_from_final_state, src/sim_propagate.cpp:1610-1630). */
+int csc_copy_final_state(csc_ctx *ctx, uint32_t n, const double *d_final_state, double *d_state);
+
+/* Activity flags (src/sim_propagate.cpp:639-647): d_active[i] = coll | conj << 1. Whitelists
+ * are host arrays of particle indices (NULL/0 = empty = everybody). */
+int csc_activity_flags(csc_ctx *ctx, uint32_t n, const double *d_state, double min_coll_radius, int with_conj,
+                       const uint64_t *coll_wl, uint64_t n_coll_wl, const uint64_t *conj_wl, uint64_t n_conj_wl,
+                       uint8_t *d_active);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -149,6 +149,10 @@ def lib():
         L.orc_sim_step_nconj.argtypes = [vp]
         L.orc_sim_get_step_conj.argtypes = [vp, vp]
         L.orc_sim_stage_times.argtypes = [vp, vp]
+        L.orc_rhofac.restype = dbl
+        L.orc_rhofac.argtypes = [u32]
+        L.orc_det_pow.restype = dbl
+        L.orc_det_pow.argtypes = [dbl, dbl]
         _LIB = L
     return _LIB
 

@@ -1,0 +1,284 @@
+"""GPU parity tests: every stage of the HIP pipeline, called through the C ABI of
+libcascade_hip.so (include/cascade_hip.h), against the CPU oracle on the same inputs.
+
+Contract (BASELINE.json north_star):
+  * bit-exact: global AABBs, Morton codes, sort permutation, BVH node arrays (canonical
+    level order, reference node layout), broad-phase pair sets -- all given identical AABBs
+    (the oracle's AABBs are injected);
+  * tolerance: substep times / Taylor coefficients / final states within 1e-9 relative;
+    collision and conjunction event SETS equal, event times and states within 1e-9 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9  # the tolerance of the north star
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cascade_amd import _capi
+
+    c = _capi.Context(0)
+    yield c
+    c.close()
+
+
+def _pop(n, seed=42, same_code=False):
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(n, seed)
+    if same_code:
+        # test/same_morton_code.cpp:65-76: particles (almost) on top of others -> equal codes
+        eps = np.finfo(float).eps
+        extra = []
+        for idx in (1, 123, 456):
+            p = st[idx].copy()
+            p[:3] += eps * 1000
+            p[6] = 0.1
+            extra.append(p)
+        st = np.concatenate([st, np.array(extra)])
+        st[:-3, 6] = 1e-6
+    return st
+
+
+def _oracle_step(orc, st, n_par_ct, **kw):
+    s = orc.Sim(st, 0.23, n_par_ct=n_par_ct, **kw)
+    oc = s.step()
+    return s, oc
+
+
+@pytest.mark.parametrize("n,n_par_ct,same_code", [(2, 1, False), (6, 3, False), (64, 1, False), (2003, 1, False), (2003, 3, False), (2003, 3, True), (20000, 2, False)])
+def test_aabb_to_pairs_bit_exact(orc, ctx, n, n_par_ct, same_code):
+    """K2b-K6 on injected (oracle) AABBs: global AABB, Morton codes, stable permutation,
+    sorted arrays, BVH nodes and broad-phase pairs are bit-identical."""
+    st = _pop(n, same_code=same_code)
+    n = len(st)
+    s, oc = _oracle_step(orc, st, n_par_ct)
+    C_ = s.nchunks
+    L, h, chk = ctx.L, ctx.h, ctx._chk
+    lbs = np.stack([s.aabbs(c)[0] for c in range(C_)])
+    ubs = np.stack([s.aabbs(c)[1] for c in range(C_)])
+    d_lbs, d_ubs = ctx.array(lbs), ctx.array(ubs)
+    d_glb, d_gub = ctx.empty((C_, 4), np.float32), ctx.empty((C_, 4), np.float32)
+    chk(L.csc_global_aabb(h, n, C_, d_lbs.ptr, d_ubs.ptr, d_glb.ptr, d_gub.ptr))
+    glb, gub = d_glb.download(), d_gub.download()
+    for c in range(C_):
+        olb, oub = s.global_aabb(c)
+        assert np.array_equal(glb[c], olb)
+        assert np.array_equal(np.nextafter(gub[c], np.float32(np.inf)), oub)  # oracle holds the bumped value
+    d_codes = ctx.empty((C_, n), np.uint64)
+    chk(L.csc_morton_encode(h, n, C_, d_lbs.ptr, d_ubs.ptr, d_glb.ptr, d_gub.ptr, d_codes.ptr))
+    chk(L.csc_check_flags(h))
+    codes = d_codes.download()
+    d_vidx, d_sc = ctx.empty((C_, n), np.uint32), ctx.empty((C_, n), np.uint64)
+    d_slb, d_sub = ctx.empty((C_, n, 4), np.float32), ctx.empty((C_, n, 4), np.float32)
+    chk(L.csc_sort_gather(h, n, C_, d_codes.ptr, d_lbs.ptr, d_ubs.ptr, d_vidx.ptr, d_sc.ptr, d_slb.ptr, d_sub.ptr))
+    vidx, sc, slb, sub = d_vidx.download(), d_sc.download(), d_slb.download(), d_sub.download()
+    chk(L.csc_bvh_build(h, n, C_, d_sc.ptr, d_slb.ptr, d_sub.ptr))
+    ca, cj = s.active_flags()
+    d_act = ctx.array((ca | (cj << 1)).astype(np.uint8))
+    npairs = C.c_uint64()
+    chk(L.csc_broad_phase(h, n, C_, d_slb.ptr, d_sub.ptr, d_vidx.ptr, d_act.ptr, C.byref(npairs)))
+    tot = 0
+    for c in range(C_):
+        ocodes, ovidx = s.codes(c)
+        assert np.array_equal(codes[c], ocodes), "Morton codes"
+        assert np.array_equal(vidx[c], ovidx), "sort permutation"
+        osc, oslb, osub = s.sorted_data(c)
+        assert np.array_equal(sc[c], osc) and np.array_equal(slb[c], oslb) and np.array_equal(sub[c], osub)
+        otree = s.bvh(c)
+        d_nodes = ctx.empty((2 * n,), orc.BVH_NODE_DTYPE)
+        nn = C.c_uint64()
+        chk(L.csc_bvh_export(h, c, d_nodes.ptr, 2 * n, C.byref(nn)))
+        tree = d_nodes.download()[: nn.value]
+        assert nn.value == len(otree), "node count"
+        for f in ("begin", "end", "parent", "left", "right", "nn_level", "split_idx", "lb", "ub"):
+            assert np.array_equal(tree[f], otree[f]), f"BVH field {f}"
+        assert tree.tobytes() == otree.tobytes()
+        obp = s.bp_pairs(c)
+        cnt = C.c_uint64()
+        got = np.empty((max(len(obp), 1) * 2 + 16, 2), dtype=np.uint32)
+        chk(L.csc_broad_phase_get(h, c, got.ctypes.data_as(C.c_void_p), len(got), C.byref(cnt)))
+        assert cnt.value == len(obp), "pair count"
+        g = got[: cnt.value]
+        g = g[np.lexsort((g[:, 1], g[:, 0]))]
+        assert np.array_equal(g, obp), "broad-phase pair set"
+        tot += cnt.value
+    assert tot == npairs.value
+
+
+def _gpu_propagate(ctx, st, cfg_kw):
+    from cascade_amd import _capi
+
+    L, h, chk = ctx.L, ctx.h, ctx._chk
+    n = len(st)
+    cfg = _capi.PropCfg()
+    for k, v in cfg_kw.items():
+        if k == "reentry_k":
+            for i in range(3):
+                cfg.reentry_k[i] = v[i]
+        else:
+            setattr(cfg, k, v)
+    Cn = cfg.nchunks
+    d_state = ctx.array(st)
+    d = dict(
+        nsub=ctx.empty(n, np.uint32),
+        status=ctx.empty(n, np.int32),
+        ev_idx=ctx.empty(n, np.uint32),
+        ev_time=ctx.empty(n, np.float64),
+        nf=ctx.empty(n, np.float64),
+        final=ctx.empty((n, 6), np.float64),
+        lbs=ctx.empty((Cn, n, 4), np.float32),
+        ubs=ctx.empty((Cn, n, 4), np.float32),
+    )
+    chk(L.csc_propagate(h, C.byref(cfg), n, d_state.ptr, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, d["final"].ptr, d["lbs"].ptr, d["ubs"].ptr))
+    summ = _capi.PropSummary()
+    chk(L.csc_propagate_summary(h, n, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, C.byref(summ)))
+    d_off = ctx.empty(n + 1, np.uint64)
+    chk(L.csc_exclusive_scan(h, d["nsub"].ptr, n, d_off.ptr))
+    tot = int(summ.total_substeps)
+    d_tcs = ctx.empty((max(tot, 1), 7, 21), np.float64)
+    d_tco = ctx.empty((max(tot, 1), 2), np.float64)
+    chk(L.csc_propagate_store(h, C.byref(cfg), n, d_state.ptr, d_off.ptr, d_tcs.ptr, d_tco.ptr))
+    out = {k: v.download() for k, v in d.items()}
+    out.update(summ=summ, off=d_off.download(), tcs=d_tcs.download()[:tot], tco=d_tco.download()[:tot])
+    out["dev"] = dict(state=d_state, off=d_off, tcs=d_tcs, tco=d_tco)
+    return out
+
+
+def _cfg_kw(orc, ct, n_par_ct, conj_thresh=0.0, t0=(0.0, 0.0), exit_radius=0.0, reentry=0.0):
+    kw = dict(dyn_kind=0, order=20, mu=1.0, rhofac=orc.lib().orc_rhofac(20), init_time_hi=t0[0], init_time_lo=t0[1], delta_t=ct * n_par_ct, ct=ct, nchunks=n_par_ct, max_substeps=0, conj_thresh=conj_thresh)
+    kw.update(has_exit=1 if exit_radius > 0 else 0, exit_c0=exit_radius * exit_radius)
+    if np.ndim(reentry) == 0:
+        kw.update(has_reentry=1 if reentry > 0 else 0, reentry_k=(1.0, 1.0, 1.0), reentry_c0=reentry * reentry)
+    else:
+        a, b, c = reentry
+        kw.update(has_reentry=1, reentry_k=((b * c) * (b * c), (a * c) * (a * c), (a * b) * (a * b)), reentry_c0=a * a * b * b * c * c)
+    return kw
+
+
+def _rel_close(a, b, rtol=RTOL, scale=None):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    sc = np.maximum(np.abs(b), 1.0 if scale is None else scale)
+    return np.all(np.abs(a - b) <= rtol * sc)
+
+
+@pytest.mark.parametrize("n,ct,n_par_ct,conj", [(64, 0.23, 1, 0.0), (2003, 0.23, 1, 0.0), (2003, 0.23, 3, 1e-4), (500, 0.23, 8, 0.0), (300, 1.7, 4, 0.0)])
+def test_propagate_parity(orc, ctx, n, ct, n_par_ct, conj):
+    """K1/K2: substep counts equal; substep times, Taylor coefficients and final states within
+    1e-9 relative (they are in fact expected bit-identical: same operation order); AABBs
+    bit-identical when the coefficients are."""
+    orc.lib().orc_rhofac.restype = C.c_double
+    orc.lib().orc_rhofac.argtypes = [C.c_uint32]
+    st = _pop(n, seed=7)
+    s = orc.Sim(st, ct, n_par_ct=n_par_ct, conj_thresh=conj)
+    s.time = 3.25
+    assert s.step() in ("success", "collision")
+    nsub, tcs, tco = s.substeps()
+    g = _gpu_propagate(ctx, st, _cfg_kw(orc, ct, n_par_ct, conj, t0=(3.25, 0.0)))
+    assert np.array_equal(g["nsub"], nsub)
+    assert np.all((g["status"] & 0xFF) == 0) and g["summ"].flags == 0
+    assert _rel_close(g["tco"][:, 0], tco[:, 0])
+    # Taylor coefficients: relative to the magnitude of the order-0 coefficient of the same variable
+    scale = np.abs(tcs[:, :, :1]) + 1.0
+    assert np.all(np.abs(g["tcs"] - tcs) <= RTOL * scale)
+    assert _rel_close(g["final"], s.final_state())
+    bit_exact = np.array_equal(g["tcs"], tcs) and np.array_equal(g["tco"], tco)
+    print("bit-exact TCs:", bit_exact)
+    if bit_exact:
+        for c in range(s.nchunks):
+            lb, ub = s.aabbs(c)
+            assert np.array_equal(g["lbs"][c], lb) and np.array_equal(g["ubs"][c], ub)
+    else:
+        for c in range(s.nchunks):
+            lb, ub = s.aabbs(c)
+            assert np.allclose(g["lbs"][c], lb, rtol=1e-6, atol=1e-6) and np.allclose(g["ubs"][c], ub, rtol=1e-6, atol=1e-6)
+
+
+def test_propagate_events_and_nf(orc, ctx):
+    """Terminal events (src/sim_basic.cpp:509-578) and non-finite states in K1."""
+    orc.lib().orc_rhofac.restype = C.c_double
+    orc.lib().orc_rhofac.argtypes = [C.c_uint32]
+    a = [1.1, 0.0, 0.0, 0.0, 0.953, 0.0, 0.0]
+    st = np.array([a, [1.5, 0.0, 0.0, 0.0, 0.01, 0.0, 0.0], a, [1.1, 0, 0, 0, 150.0, 0, 0], a, a])
+    s = orc.Sim(st, 0.23, n_par_ct=3, reentry_radius=1.0, exit_radius=10.0)
+    oc = s.step()
+    g = _gpu_propagate(ctx, st, _cfg_kw(orc, 0.23, 3, exit_radius=10.0, reentry=1.0))
+    nsub, tcs, tco = s.substeps()
+    assert np.array_equal(g["nsub"], nsub)
+    assert (g["status"][3] & 0xFF) == 1 and g["ev_idx"][3] == 0  # exit
+    assert oc == "exit" and s.interrupt_info == 3
+    assert g["summ"].n_ste == 1 and g["summ"].ste_idx == 3
+    assert _rel_close(g["tco"][:, 0], tco[:, 0])
+    # non-finite state
+    st2 = st.copy()
+    st2[2, 0] = np.inf
+    g = _gpu_propagate(ctx, st2, _cfg_kw(orc, 0.23, 1))
+    assert (g["status"][2] & 0xFF) == 2 and g["summ"].n_nf == 1 and g["summ"].nf_idx == 2 and g["summ"].nf_time == 0.0
+
+
+@pytest.mark.parametrize("n,n_par_ct,conj", [(2003, 1, 0.0), (2003, 3, 2e-3), (3000, 8, 1e-3)])
+def test_narrow_phase_injected(orc, ctx, n, n_par_ct, conj):
+    """K7 on the oracle's Taylor coefficients and the oracle's broad-phase pairs: collision and
+    conjunction sets equal, times/distances/states within 1e-9 relative."""
+    st = _pop(n, seed=11)
+    st[:, 6] *= 2000.0  # bigger objects -> some collisions in one superstep
+    s = orc.Sim(st, 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
+    s.time = 1.5
+    oc = s.step()
+    nsub, tcs, tco = s.substeps()
+    off = np.concatenate([[0], np.cumsum(nsub)]).astype(np.uint64)
+    pairs = [s.bp_pairs(c) for c in range(s.nchunks)]
+    poff = np.concatenate([[0], np.cumsum([len(p) for p in pairs])]).astype(np.uint64)
+    allp = np.concatenate(pairs) if poff[-1] else np.zeros((0, 2), np.uint32)
+    ca, cj = s.active_flags()
+    L, h, chk = ctx.L, ctx.h, ctx._chk
+    d_state, d_act = ctx.array(st), ctx.array((ca | (cj << 1)).astype(np.uint8))
+    d_off, d_tcs, d_tco, d_pairs = ctx.array(off), ctx.array(tcs), ctx.array(tco), ctx.array(allp)
+    ncoll, nconj, warn = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    chk(
+        L.csc_narrow_phase_pairs(
+            h, n, s.nchunks, 0.23, s.delta_t, 1.5, 0.0, conj, 20, d_state.ptr, d_act.ptr, d_off.ptr, d_tcs.ptr, d_tco.ptr, d_pairs.ptr, poff.ctypes.data_as(C.c_void_p), C.byref(ncoll), C.byref(nconj), C.byref(warn)
+        )
+    )
+    from cascade_amd import _capi
+
+    coll = np.empty(ncoll.value, dtype=_capi.COLL_DTYPE)
+    cj_ = np.empty(nconj.value, dtype=_capi.CONJ_DTYPE)
+    chk(L.csc_narrow_phase_get(h, coll.ctypes.data_as(C.c_void_p), len(coll), cj_.ctypes.data_as(C.c_void_p), len(cj_)))
+    ocoll, oconj = s.collisions(), s.step_conjunctions()
+    print("pairs", poff[-1], "collisions", len(ocoll), "conjunctions", len(oconj), "outcome", oc)
+    assert len(coll) == len(ocoll) and len(cj_) == len(oconj)
+    key = lambda a: np.lexsort((a["j"], a["i"], a["time"]))
+    coll, ocoll = coll[key(coll)], ocoll[key(ocoll)]
+    assert np.array_equal(coll["i"], ocoll["i"]) and np.array_equal(coll["j"], ocoll["j"])
+    assert _rel_close(coll["time"], ocoll["time"])
+    cj_, oconj = cj_[key(cj_)], oconj[key(oconj)]
+    assert np.array_equal(cj_["i"], oconj["i"]) and np.array_equal(cj_["j"], oconj["j"])
+    assert _rel_close(cj_["time"], oconj["time"]) and _rel_close(cj_["state_i"], oconj["state_i"]) and _rel_close(cj_["state_j"], oconj["state_j"])
+    assert np.all(np.abs(cj_["dist"] - oconj["dist"]) <= 1e-9)
+    if n_par_ct == 1 and conj == 0.0:
+        assert len(ocoll) > 0, "test population should produce collisions"
+
+
+def test_dense_output(orc, ctx):
+    """K8 vs the oracle's dense_propagate (via an interrupted step)."""
+    orc.lib().orc_rhofac.restype = C.c_double
+    orc.lib().orc_rhofac.argtypes = [C.c_uint32]
+    st = _pop(500, seed=3)
+    g = _gpu_propagate(ctx, st, _cfg_kw(orc, 0.23, 4))
+    L, h, chk = ctx.L, ctx.h, ctx._chk
+    d_out = ctx.empty((500, 6), np.float64)
+    # state at t = full superstep must reproduce the final state to rounding
+    chk(L.csc_dense_propagate(h, 500, 20, 0.92, g["dev"]["off"].ptr, g["dev"]["tcs"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
+    chk(L.csc_check_flags(h))
+    assert np.allclose(d_out.download(), g["final"], rtol=0, atol=1e-14)
+    # mid-superstep: compare with an oracle propagate_until (which uses dense output)
+    s = orc.Sim(st, 0.23, n_par_ct=4)
+    assert s.propagate_until(0.5) == "time_limit"
+    chk(L.csc_dense_propagate(h, 500, 20, 0.5, g["dev"]["off"].ptr, g["dev"]["tcs"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
+    assert _rel_close(d_out.download(), s.state[:, :6])

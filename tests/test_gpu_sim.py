@@ -1,0 +1,213 @@
+"""GPU: the reference's known-answer tests run against cascade_amd.sim (the drop-in for
+cascade.sim, cascade.py/core.cpp:87-330), and whole-step parity against the CPU oracle on
+random populations (event sets equal, times and states within 1e-9 relative)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PSIZE = 1.57e-8
+PI = math.pi
+RTOL = 1e-9
+
+
+def k2c(orc, kep):
+    x, v = orc.kep_to_cart_test(kep, 1.0)
+    return list(x) + list(v)
+
+
+def test_python_conjunction_kat():
+    """cascade.py/test.py:155-208."""
+    from cascade_amd import sim
+
+    r1 = (0.3342377271241684, 0.942488801930755, 0.0)
+    v1 = (0.009424730938644767, -0.003342321565239028, 0.9999500004176654)
+    r2 = (-0.15179985849820377, -0.988411251938142, 0.0)
+    v2 = (6.052273379648475e-17, -9.295060541060909e-18, 1.000000000001)
+    s = sim([list(r1) + list(v1) + [PSIZE], list(r2) + list(v2) + [PSIZE]], 0.23, conj_thresh=PSIZE * 100000000)
+    cv0 = s.conjunctions
+    assert len(cv0) == 0
+    s.propagate_until(2.0)
+    cv1 = s.conjunctions
+    assert len(cv1) == 1
+    s.propagate_until(20.0)
+    cv2 = s.conjunctions
+    assert len(cv2) == 6
+    s.reset_conjunctions()
+    assert len(s.conjunctions) == 0
+    del s
+    assert len(cv0) == 0 and len(cv1) == 1 and len(cv2) == 6
+    assert np.all(cv2["dist"] == cv2["dist"])
+    with pytest.raises(ValueError):
+        cv2["dist"][0] = 0
+
+
+@pytest.mark.parametrize("n_par_ct", [1, 3])
+def test_multiple_conjs_and_discard(orc, n_par_ct):
+    """test/conj_tracking.cpp:228-297."""
+    from cascade_amd import outcome, sim
+
+    p1 = k2c(orc, (1.0, 0.000005, PI / 2 + 1e-6, 0, 1.23, 0))
+    p2 = k2c(orc, (1.0, 0.000005, PI / 2, 0, 4.56, 0))
+    p3 = k2c(orc, (1.0 + 1e-7, 0.0, 0.0, 0.0, 0.0, 0))
+    p4 = list(p3)
+    p4[0] = -p4[0] + 1e-6
+    s = sim([p1 + [PSIZE], p2 + [PSIZE], p3 + [PSIZE], p4 + [PSIZE]], 0.23, conj_thresh=PSIZE * 100, n_par_ct=n_par_ct)
+    while True:
+        assert s.step() == outcome.success
+        if s.time > 26.0:
+            break
+    c = s.conjunctions
+    assert len(c) == 8 and np.all(np.diff(c["time"]) >= 0) and c["time"][-1] < s.time
+    p4[0] = -p3[0]
+    s = sim([p1 + [PSIZE], p2 + [PSIZE], p3 + [PSIZE], p4 + [PSIZE]], 0.23, conj_thresh=PSIZE * 100, n_par_ct=n_par_ct)
+    while True:
+        oc = s.step()
+        if oc != outcome.success:
+            assert oc == outcome.collision
+            break
+    c = s.conjunctions
+    assert len(c) == 1 and c[0]["i"] == 0 and c[0]["j"] == 1 and c[0]["time"] < s.time
+
+
+@pytest.mark.parametrize("n_par_ct", [1, 3])
+def test_interrupt_order(n_par_ct):
+    """test/interrupt_order.cpp:25-130."""
+    from cascade_amd import outcome, sim
+
+    s = sim([[0.99, 0, 0, 1, 0, 0, 1e-6], [1.01, 0, 0, -1, 0, 0, 1e-6], [4.9, 0, 0, 1, 0, 0, 1e-6]], 0.23, exit_radius=5.0, reentry_radius=0.75, n_par_ct=n_par_ct)
+    d2 = lambda a, b: float(np.sum((s.state[a, :3] - s.state[b, :3]) ** 2))
+    r2 = lambda a: float(np.sum(s.state[a, :3] ** 2))
+    assert s.propagate_until(1000.0) == outcome.collision
+    assert s.interrupt_info == (0, 1) and abs(d2(0, 1) - 4e-12) < 1e-14
+
+    def rerun(st):
+        s.state[:] = np.array(st)
+        s.time = 0.0
+        return s.propagate_until(1000.0)
+
+    assert rerun([[0.99, 0, 0, 1, 0, 0, 1e-6], [1.01, 0, 0, -1, 0, 0, 1e-6], [4.9, 0, 0, 1000, 0, 0, 1e-6]]) == outcome.exit
+    assert s.interrupt_info == 2 and abs(r2(2) - 25.0) < 1e-14
+    assert rerun([[0.99, 0, 0, 1, 0, 0, 1e-6], [1.01, 0, 0, -1, 0, 0, 1e-6], [0.76, 0, 0, 0, 0, 0, 1e-6]]) == outcome.collision
+    assert s.interrupt_info == (0, 1) and abs(d2(0, 1) - 4e-12) < 1e-14
+    assert rerun([[0.99, 0, 0, 1, 0, 0, 1e-6], [1.01, 0, 0, -1, 0, 0, 1e-6], [0.76, 0, 0, -1, 0, 0, 1e-6]]) == outcome.reentry
+    assert s.interrupt_info == 2 and abs(r2(2) - 0.75 * 0.75) < 1e-14
+    assert rerun([[0.76, 0, 0, -1, 0, 0, 1e-6], [1.0, 0, 0, 0, 1, 0, 1e-6], [2, 0, 0, 1, 0, 0, 1e-6]]) == outcome.reentry
+    assert s.interrupt_info == 0 and abs(r2(0) - 0.75 * 0.75) < 1e-14
+    assert rerun([[0.76, 0, 0, 0, 0, 0, 1e-6], [1.0, 0, 0, 0, 1, 0, 1e-6], [4.9, 0, 0, 1, 0, 0, 1e-6]]) == outcome.exit
+    assert s.interrupt_info == 2 and abs(r2(2) - 25.0) < 1e-14
+
+
+@pytest.mark.parametrize("n_par_ct", [1, 3])
+def test_single_collision_and_reentry(orc, n_par_ct):
+    """test/single_collision.cpp:35-117, test/reentry.cpp:98-215, test/invalid_state.cpp."""
+    from cascade_amd import outcome, sim
+
+    eps = np.finfo(float).eps
+    p1 = k2c(orc, (1.05, 0.05, PI / 2, 0, 1.23, 0))
+    p2 = k2c(orc, (1.05, 0.05, PI / 2, 0, 4.56, 0))
+    s0 = np.array([p1 + [PSIZE], p2 + [PSIZE]])
+    s = sim(s0, 0.23, n_par_ct=n_par_ct)
+    while s.step() != outcome.collision:
+        pass
+    assert s.interrupt_info == (0, 1)
+    assert float(np.sum((s.state[0, :3] - s.state[1, :3]) ** 2)) - 4 * PSIZE * PSIZE < eps * 10
+    s.state[:] = s0
+    s.time = 0
+    assert s.propagate_until(0.5) == outcome.time_limit and s.interrupt_info is None and s.time == 0.5
+    s.state[:] = s0
+    s.time = 0
+    assert s.propagate_until(1.57) == outcome.time_limit and abs(s.time - 1.57) < 1e-15
+
+    s = sim([[1.5, 0, 0, 0, 0.0, 0.0, 0]], 0.23, reentry_radius=[1.0, 1.1, 1.2], n_par_ct=n_par_ct)
+    rn = lambda i: float(np.sqrt(np.sum(s.state[i, :3] ** 2)))
+    assert s.propagate_until(1000.0) == outcome.reentry and abs(rn(0) - 1.0) < 1e-14
+    s.state[:] = [[0.0, 1.5, 0, 0, 0.0, 0.0, 0]]
+    s.time = 0.0
+    assert s.propagate_until(1000) == outcome.reentry and abs(rn(0) - 1.1) < 1e-14
+    c = [0.0, 2.1, 0.0, 0.69, 0.0, 0.0, 0.0]
+    s.set_new_state_pars([c, c, c, [0.0, 1.5, 0.0, 0.0, 0.0, 0.0, 0.0], c, c])
+    s.time = 0.0
+    assert s.propagate_until(1000) == outcome.reentry and s.interrupt_info == 3 and abs(rn(3) - 1.1) < 1e-14
+
+    # invalid states: nothing user-visible changes (src/sim_propagate.cpp:513-515)
+    e1 = k2c(orc, (1.05, 0.0, 0.0, 0.0, 0.0, 0))
+    e2 = list(e1)
+    e2[0] = -e2[0]
+    s0 = np.array([e1 + [PSIZE], e2 + [PSIZE]])
+    s = sim(s0, 0.23)
+    s.state[0, 6] = -1
+    with pytest.raises(ValueError, match="An invalid particle size of -1 was detected for the particle at index 0"):
+        s.step()
+    s.state[0, 6] = PSIZE
+    assert np.array_equal(s.state, s0) and s.time == 0.0
+    s.state[0, 0] = np.inf
+    assert s.step() == outcome.err_nf_state and s.interrupt_info == (0, 0.0)
+    s.state[0, 0] = s0[0, 0]
+    assert np.array_equal(s.state, s0) and s.time == 0.0
+
+
+@pytest.mark.parametrize("n_par_ct", [1, 3])
+def test_conj_filtering_counts(orc, n_par_ct):
+    """test/coll_conj_filter.cpp:95-179: conjunction counts 0, 3, 3, 6, 3, 3."""
+    from cascade_amd import outcome, sim
+
+    p1 = k2c(orc, (1.0, 0.000005, PI / 2, 0, 1.23, 0))
+    p2 = k2c(orc, (1.0, 0.000005, PI / 2, 0, 4.56, 0))
+    p3 = k2c(orc, (1.05, 0.0, 0.0, 0.0, 0.0, 0))
+    p4 = list(p3)
+    p4[0] = -p4[0]
+    ic = np.array([p1 + [PSIZE], p2 + [PSIZE]])
+    ic4 = np.array([p1 + [PSIZE], p2 + [PSIZE], p3 + [PSIZE], p4 + [PSIZE]])
+    s = sim(ic, 0.23, min_coll_radius=float("inf"), n_par_ct=n_par_ct)
+    assert s.propagate_until(10.0) == outcome.time_limit and len(s.conjunctions) == 0
+
+    def run(st, wl, expect):
+        s.time = 0
+        s.set_new_state_pars(st)
+        s.conj_whitelist = wl
+        s.reset_conjunctions()
+        assert s.propagate_until(10.0) == outcome.time_limit
+        assert len(s.conjunctions) == expect
+        return s.conjunctions
+
+    s.conj_thresh = PSIZE / 2
+    run(ic, set(), 3)
+    run(ic, {0}, 3)
+    run(ic4, set(), 6)
+    c = run(ic4, {0}, 3)
+    assert np.all(c["i"] == 0) and np.all(c["j"] == 1)
+    c = run(ic4, {2, 3}, 3)
+    assert np.all(c["i"] == 2) and np.all(c["j"] == 3)
+
+
+@pytest.mark.parametrize("n,n_par_ct,conj,scale", [(3000, 1, 0.0, 1.0), (3000, 3, 1e-3, 1.0), (2000, 4, 0.0, 3000.0)])
+def test_steps_vs_oracle(orc, n, n_par_ct, conj, scale):
+    """Whole-step parity with the CPU oracle over several supersteps: same outcomes and
+    interrupt info, same conjunction sets, times and states within 1e-9 relative."""
+    from cascade_amd import sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(n, seed=5)
+    st[:, 6] *= scale
+    g = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
+    o = orc.Sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
+    n_int = 0
+    for _ in range(6):
+        og, oo = g.step(), o.step()
+        assert og.name == oo
+        assert g.interrupt_info == o.interrupt_info
+        n_int += og.name != "success"
+        assert abs(g.time - o.time) <= RTOL * max(1.0, abs(o.time))
+        assert np.all(np.abs(g.state - o.state) <= RTOL * np.maximum(1.0, np.abs(o.state)))
+        assert g.last_bp_pairs == int(o.stage_times()["n_bp_pairs"])
+    cg, co = g.conjunctions, o.conjunctions
+    assert len(cg) == len(co)
+    if len(co):
+        assert np.array_equal(cg["i"], co["i"]) and np.array_equal(cg["j"], co["j"])
+        assert np.all(np.abs(cg["time"] - co["time"]) <= RTOL * np.maximum(1.0, np.abs(co["time"])))
+        assert np.all(np.abs(cg["dist"] - co["dist"]) <= 1e-9)
+    if scale > 1:
+        assert n_int > 0, "the scaled population should produce collisions"
