@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- object-days propagated per second, collision detection included.
+
+Workload (BASELINE.json configs[1]): the random LEO Kepler population of
+benchmark/random_leo_pop_kep.cpp scaled to 1,000,000 objects on one MI355X, ct = 0.23,
+n_par_ct = 1, Keplerian dynamics mu = 1 (1 TU = 806.81 s). A "step" is one sim.step()
+(propagate -> AABB -> Morton -> sort -> BVH -> broad phase -> narrow phase -> outcome)
+with the state already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, each rank runs the full pipeline on its OWN 1M-object
+population (seed 42 + rank): independent replicas, weak scaling, no data-path collective
+(the cross-GPU exchange of the north star is not built yet).
+
+Prints ONE JSON line (rank 0) with the contract fields plus "roofline" (dominant kernel,
+algorithmic bytes / HIP-event kernel time) and, at N = 1, "cpu_baseline" (the CPU oracle,
+an OpenMP port of the reference's algorithms, timed on a bounded sample on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+TU_SECONDS = 806.81  # test/last_bit_flip.cpp:61
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VEC_PEAK_TFLOPS = 78.6
+
+# Algorithmic bytes per unit, P = 20.
+BYTES = {
+    "k_propagate_store": lambda u: u["substeps"] * (1176 + 16) + u["n"] * 56,
+    "k_propagate": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28),
+    "k_narrow_phase": lambda u: u["pair_intervals"] * (1008 + 32 + 8),
+    "k_broad_phase_count": lambda u: u["n"] * u["nchunks"] * 36 * 2,  # lower bound: own AABB + root
+    "k_broad_phase_write": lambda u: u["pairs"] * 8 + u["n"] * u["nchunks"] * 36 * 2,
+    "k_rs_scatter": lambda u: u["sort_keys"] * 24,
+    "k_rs_hist": lambda u: u["sort_keys"] * 8,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nparts", type=int, default=1_000_000)
+    ap.add_argument("--ct", type=float, default=0.23)
+    ap.add_argument("--n-par-ct", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group(backend="nccl")
+        dist = dist_
+
+    from cascade_amd import outcome, sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    N = args.nparts
+    st = random_leo_pop_kep(N, seed=42 + rank)
+    s = sim(st, args.ct, n_par_ct=args.n_par_ct, device=local_rank)
+    s.host_sync = False  # state stays resident in HBM between steps
+    s.upload_state()
+    s.stage_ms = None
+
+    def barrier():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+        s._ctx.sync()
+
+    for _ in range(args.warmup):
+        s.step()
+
+    s._ctx.profile(True)
+    s._ctx.profile_reset()
+    pairs = 0
+    outcomes = {}
+    t_sim0 = s.time
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        oc = s.step()
+        outcomes[oc.name] = outcomes.get(oc.name, 0) + 1
+        pairs += s.last_bp_pairs
+    barrier()
+    wall = time.perf_counter() - t0
+    prof = s._ctx.profile_get()
+    s._ctx.profile(False)
+    sim_time = s.time - t_sim0
+
+    wall_max = wall
+    tot_obj_days = N * sim_time * TU_SECONDS / 86400.0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_max = float(t.item())
+        od = torch.tensor([tot_obj_days], dtype=torch.float64, device="cuda")
+        dist.all_reduce(od, op=dist.ReduceOp.SUM)
+        tot_obj_days = float(od.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = tot_obj_days / wall_max
+    # Dominant kernel + roofline from the HIP-event timings of the timed region.
+    kern = {k: v for k, v in prof.items()}
+    tot_kernel_ms = sum(v[1] for v in kern.values())
+    dom = max(kern, key=lambda k: kern[k][1])
+    units = dict(n=N, nchunks=args.n_par_ct, substeps=N * args.n_par_ct if args.n_par_ct == 1 else None, pairs=pairs / args.steps, pair_intervals=pairs / args.steps, sort_keys=N * args.n_par_ct)
+    launches, ms = kern[dom]
+    per_step_launches = launches / args.steps
+    avg_ms = ms / launches
+    roof = None
+    if dom in BYTES and units.get("substeps") is not None:
+        alg_bytes_per_step = BYTES[dom](units)
+        alg_bytes_per_launch = alg_bytes_per_step / per_step_launches
+        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(avg_ms, 5), algorithmic_bytes_per_launch=int(alg_bytes_per_launch))
+    else:
+        roof = dict(bound="hbm", kernel=dom, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, avg_launch_ms=round(avg_ms, 5))
+
+    out = {
+        "metric": "object-days propagated/sec incl. collision detection",
+        "value": round(value, 2),
+        "unit": "object-days/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall_max / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "random_leo_pop_kep scaled to %d objects per GPU (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, args.ct, args.n_par_ct),
+            "nparts_per_gpu": N,
+            "ct": args.ct,
+            "n_par_ct": args.n_par_ct,
+            "parallelism": "replicas x%d" % world,
+            "outcomes": outcomes,
+            "bp_pairs_per_step": pairs / args.steps,
+            "sim_time_advanced_TU": sim_time,
+        },
+        "roofline": roof,
+        "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+        "kernel_ms_total_per_step": round(tot_kernel_ms / args.steps, 4),
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/: an OpenMP port of the reference's algorithms, kind "port")
+    timed on a bounded sample of the same workload: the first cpu_sample objects of the same
+    population, 2 steps after 1 warm-up step. The broad/narrow phase cost per object grows
+    with the population density, so the full-size CPU rate is LOWER than this sample's."""
+    from cascade_amd.workloads import random_leo_pop_kep
+    from oracle import orc_py
+
+    orc_py.build()
+    n = min(args.cpu_sample, args.nparts)
+    st = random_leo_pop_kep(args.nparts, seed=42)[:n]
+    s = orc_py.Sim(st, args.ct, n_par_ct=args.n_par_ct)
+    s.step()
+    t_sim0 = s.time
+    t0 = time.perf_counter()
+    nsteps = 2
+    for _ in range(nsteps):
+        s.step()
+    wall = time.perf_counter() - t0
+    od = n * (s.time - t_sim0) * TU_SECONDS / 86400.0
+    return {
+        "value": round(od / wall, 2),
+        "unit": "object-days/s",
+        "cores": int(orc_py.lib().orc_num_threads()),
+        "kind": "port",
+        "sample": "first %d objects of the same seeded population, %d steps of ct=%g x n_par_ct=%d (%.3f s of CPU wall)" % (n, nsteps, args.ct, args.n_par_ct, wall),
+        "stage_times_last_step_s": s.stage_times(),
+    }
+
+
+if __name__ == "__main__":
+    main()

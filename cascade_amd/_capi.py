@@ -88,6 +88,9 @@ SYMBOLS = {
     "csc_sync": (_i32, [_vp]),
     "csc_timer_begin": (_i32, [_vp]),
     "csc_timer_end": (_i32, [_vp, C.POINTER(C.c_float)]),
+    "csc_profile_enable": (_i32, [_vp, _i32]),
+    "csc_profile_reset": (_i32, [_vp]),
+    "csc_profile_get": (_i32, [_vp, C.c_char_p, _sz]),
     "csc_propagate": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 9),
     "csc_propagate_summary": (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(PropSummary)]),
     "csc_exclusive_scan": (_i32, [_vp, _vp, _u64, _vp]),
@@ -184,6 +187,22 @@ class Context:
 
     def sync(self):
         self._chk(self.L.csc_sync(self.h))
+
+    def profile(self, on=True):
+        self._chk(self.L.csc_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.csc_profile_reset(self.h))
+
+    def profile_get(self):
+        """{kernel: (launches, total_ms)} since the last reset."""
+        buf = C.create_string_buffer(16384)
+        self._chk(self.L.csc_profile_get(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            out[name] = (int(n), float(ms))
+        return out
 
     def timer_begin(self):
         self._chk(self.L.csc_timer_begin(self.h))

@@ -54,6 +54,53 @@ struct csc_ctx {
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
     std::vector<csc_conjunction> conj;
+    // per-kernel HIP-event timing (csc_profile_*)
+    struct ktimer {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+        size_t used = 0;
+        double total_ms = 0;
+        uint64_t launches = 0;
+    };
+    std::map<std::string, ktimer> kt;
+    bool profiling = false;
+    void kt_begin(const char *name)
+    {
+        if (!profiling) {
+            return;
+        }
+        auto &t = kt[name];
+        if (t.used == t.evs.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            t.evs.emplace_back(a, b);
+        }
+        (void)hipEventRecord(t.evs[t.used].first, stream);
+    }
+    void kt_end(const char *name)
+    {
+        if (!profiling) {
+            return;
+        }
+        auto &t = kt[name];
+        (void)hipEventRecord(t.evs[t.used].second, stream);
+        ++t.used;
+    }
+    void kt_collect()
+    {
+        (void)hipStreamSynchronize(stream);
+        for (auto &kv : kt) {
+            auto &t = kv.second;
+            for (size_t i = 0; i < t.used; ++i) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, t.evs[i].first, t.evs[i].second) == hipSuccess) {
+                    t.total_ms += ms;
+                    ++t.launches;
+                }
+            }
+            t.used = 0;
+        }
+    }
 
     int fail(hipError_t e, const char *what)
     {
@@ -104,6 +151,13 @@ struct csc_ctx {
         if (e_ != hipSuccess) {                                                                                        \
             return ctx->fail(e_, "kernel launch");                                                                     \
         }                                                                                                              \
+    } while (0)
+
+#define KT(name, ...)                                                                                                  \
+    do {                                                                                                               \
+        ctx->kt_begin(name);                                                                                           \
+        __VA_ARGS__;                                                                                                   \
+        ctx->kt_end(name);                                                                                             \
     } while (0)
 
 #define CSC_BUF(var, T, name, count)                                                                                   \
@@ -390,6 +444,42 @@ int csc_timer_end(csc_ctx *ctx, float *ms)
     return CSC_OK;
 }
 
+int csc_profile_enable(csc_ctx *ctx, int on)
+{
+    ctx->kt_collect();
+    ctx->profiling = on != 0;
+    return CSC_OK;
+}
+
+int csc_profile_reset(csc_ctx *ctx)
+{
+    ctx->kt_collect();
+    for (auto &kv : ctx->kt) {
+        kv.second.total_ms = 0;
+        kv.second.launches = 0;
+    }
+    return CSC_OK;
+}
+
+int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap)
+{
+    ctx->kt_collect();
+    std::string out;
+    for (const auto &kv : ctx->kt) {
+        if (kv.second.launches) {
+            char line[256];
+            std::snprintf(line, sizeof(line), "%s %llu %.6f\n", kv.first.c_str(),
+                          static_cast<unsigned long long>(kv.second.launches), kv.second.total_ms);
+            out += line;
+        }
+    }
+    if (cap) {
+        std::strncpy(buf, out.c_str(), cap - 1);
+        buf[cap - 1] = 0;
+    }
+    return CSC_OK;
+}
+
 int csc_check_flags(csc_ctx *ctx)
 {
     int h[2] = {0, 0};
@@ -433,9 +523,9 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
     const bool events = cfg->has_exit || cfg->has_reentry;
     const dim3 grid(cdiv(n, 64)), block(64);
     if (events) {
-        hipLaunchKernelGGL((csc::k_propagate<20, true, false>), grid, block, 0, ctx->stream, p);
+        KT("k_propagate", hipLaunchKernelGGL((csc::k_propagate<20, true, false>), grid, block, 0, ctx->stream, p));
     } else {
-        hipLaunchKernelGGL((csc::k_propagate<20, false, false>), grid, block, 0, ctx->stream, p);
+        KT("k_propagate", hipLaunchKernelGGL((csc::k_propagate<20, false, false>), grid, block, 0, ctx->stream, p));
     }
     CSC_LAUNCH_CHECK();
     return CSC_OK;
@@ -454,9 +544,9 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
     const bool events = cfg->has_exit || cfg->has_reentry;
     const dim3 grid(cdiv(n, 64)), block(64);
     if (events) {
-        hipLaunchKernelGGL((csc::k_propagate<20, true, true>), grid, block, 0, ctx->stream, p);
+        KT("k_propagate_store", hipLaunchKernelGGL((csc::k_propagate<20, true, true>), grid, block, 0, ctx->stream, p));
     } else {
-        hipLaunchKernelGGL((csc::k_propagate<20, false, true>), grid, block, 0, ctx->stream, p);
+        KT("k_propagate_store", hipLaunchKernelGGL((csc::k_propagate<20, false, true>), grid, block, 0, ctx->stream, p));
     }
     CSC_LAUNCH_CHECK();
     return CSC_OK;
@@ -468,8 +558,8 @@ int csc_propagate_summary(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, cons
 {
     const unsigned nb = std::min(cdiv(n, SUM_BLOCK), 1024u);
     CSC_BUF(d_part, sum_partial, "sum_partial", nb);
-    hipLaunchKernelGGL(k_prop_summary, dim3(nb), dim3(SUM_BLOCK), 0, ctx->stream, n, d_nsub, d_status, d_ev_idx,
-                       d_ev_time, d_nf_last_t, d_part);
+    KT("k_prop_summary", hipLaunchKernelGGL(k_prop_summary, dim3(nb), dim3(SUM_BLOCK), 0, ctx->stream, n, d_nsub, d_status, d_ev_idx,
+                       d_ev_time, d_nf_last_t, d_part));
     CSC_LAUNCH_CHECK();
     std::vector<sum_partial> h(nb);
     CSC_HIP(hipMemcpyAsync(h.data(), d_part, nb * sizeof(sum_partial), hipMemcpyDeviceToHost, ctx->stream));
@@ -506,15 +596,15 @@ static int scan_impl(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint32_t ns
     const unsigned nb = std::max(1u, cdiv(n, csc::SCAN_TILE));
     CSC_BUF(d_bs, uint64_t, "scan_block_sums", static_cast<size_t>(nb) * nseg);
     CSC_BUF(d_tot, uint64_t, "scan_totals", nseg);
-    hipLaunchKernelGGL(csc::k_scan_block_sums, dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in, n, d_bs);
-    hipLaunchKernelGGL(csc::k_scan_sums, dim3(nseg), dim3(1024), 0, ctx->stream, d_bs, static_cast<uint64_t>(nb),
-                       d_tot);
+    KT("k_scan_block_sums", hipLaunchKernelGGL(csc::k_scan_block_sums, dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in, n, d_bs));
+    KT("k_scan_sums", hipLaunchKernelGGL(csc::k_scan_sums, dim3(nseg), dim3(1024), 0, ctx->stream, d_bs, static_cast<uint64_t>(nb),
+                       d_tot));
     if (d_out64) {
-        hipLaunchKernelGGL((csc::k_scan_final<uint64_t>), dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in,
-                           n, d_bs, d_out64, d_tot);
+        KT("k_scan_final", hipLaunchKernelGGL((csc::k_scan_final<uint64_t>), dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in,
+                           n, d_bs, d_out64, d_tot));
     } else {
-        hipLaunchKernelGGL((csc::k_scan_final<uint32_t>), dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in,
-                           n, d_bs, d_out32, d_tot);
+        KT("k_scan_final", hipLaunchKernelGGL((csc::k_scan_final<uint32_t>), dim3(nb, nseg), dim3(csc::SCAN_BLOCK), 0, ctx->stream, d_in,
+                           n, d_bs, d_out32, d_tot));
     }
     CSC_LAUNCH_CHECK();
     return CSC_OK;
@@ -530,10 +620,10 @@ int csc_global_aabb(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_l
 {
     const unsigned nb = std::min(cdiv(n, csc::GA_BLOCK * 4), static_cast<unsigned>(csc::GA_MAX_PARTIAL));
     CSC_BUF(d_part, float4, "gaabb_partial", static_cast<size_t>(nb) * nchunks * 2u);
-    hipLaunchKernelGGL(csc::k_gaabb_partial, dim3(nb, nchunks), dim3(csc::GA_BLOCK), 0, ctx->stream,
-                       reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n, d_part);
-    hipLaunchKernelGGL(csc::k_gaabb_final, dim3(nchunks), dim3(64), 0, ctx->stream, d_part, nb,
-                       reinterpret_cast<float4 *>(d_glb), reinterpret_cast<float4 *>(d_gub));
+    KT("k_gaabb_partial", hipLaunchKernelGGL(csc::k_gaabb_partial, dim3(nb, nchunks), dim3(csc::GA_BLOCK), 0, ctx->stream,
+                       reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n, d_part));
+    KT("k_gaabb_final", hipLaunchKernelGGL(csc::k_gaabb_final, dim3(nchunks), dim3(64), 0, ctx->stream, d_part, nb,
+                       reinterpret_cast<float4 *>(d_glb), reinterpret_cast<float4 *>(d_gub)));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -543,10 +633,10 @@ int csc_global_aabb(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_l
 int csc_morton_encode(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs,
                       const float *d_glb, const float *d_gub, uint64_t *d_codes)
 {
-    hipLaunchKernelGGL(csc::k_morton, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
+    KT("k_morton", hipLaunchKernelGGL(csc::k_morton, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n,
                        reinterpret_cast<const float4 *>(d_glb), reinterpret_cast<const float4 *>(d_gub), d_codes,
-                       ctx->d_flags);
+                       ctx->d_flags));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -563,11 +653,11 @@ static int radix_sort(csc_ctx *ctx, uint32_t n, uint32_t nseg, int nbits, uint64
     uint32_t *vin = vals_a, *vout = vals_b;
     bool iota = vals_iota;
     for (int shift = 0; shift < nbits; shift += 8) {
-        hipLaunchKernelGGL(csc::k_rs_hist, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin, n, shift,
-                           d_hist, nblocks);
-        hipLaunchKernelGGL(csc::k_rs_scan, dim3(nseg), dim3(1024), 0, ctx->stream, d_hist, nblocks);
-        hipLaunchKernelGGL(csc::k_rs_scatter, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
-                           iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks);
+        KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin, n, shift,
+                           d_hist, nblocks));
+        KT("k_rs_scan", hipLaunchKernelGGL(csc::k_rs_scan, dim3(nseg), dim3(1024), 0, ctx->stream, d_hist, nblocks));
+        KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
+                           iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks));
         CSC_LAUNCH_CHECK();
         std::swap(kin, kout);
         std::swap(vin, vout);
@@ -597,9 +687,9 @@ int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *
         CSC_HIP(hipMemcpyAsync(d_srt_codes, kres, tot * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     CSC_HIP(hipMemcpyAsync(d_vidx, vres, tot * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(csc::k_gather_aabb, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
+    KT("k_gather_aabb", hipLaunchKernelGGL(csc::k_gather_aabb, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), d_vidx, n,
-                       reinterpret_cast<float4 *>(d_srt_lbs), reinterpret_cast<float4 *>(d_srt_ubs));
+                       reinterpret_cast<float4 *>(d_srt_lbs), reinterpret_cast<float4 *>(d_srt_ubs)));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -658,14 +748,14 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     BB(n_nodes, uint32_t, nchunks)
 #undef BB
     const dim3 gp(cdiv(n, 256), nchunks), gn(cdiv(nn_max, 256), nchunks), blk(256);
-    hipLaunchKernelGGL(csc::k_bvh_heads, gp, blk, 0, ctx->stream, b);
+    KT("k_bvh_heads", hipLaunchKernelGGL(csc::k_bvh_heads, gp, blk, 0, ctx->stream, b));
     if (const int rc = scan_impl(ctx, b.head, n, nchunks, nullptr, b.excl)) {
         return rc;
     }
-    hipLaunchKernelGGL(csc::k_bvh_run_start, gp, blk, 0, ctx->stream, b);
-    hipLaunchKernelGGL(csc::k_bvh_karras, gp, blk, 0, ctx->stream, b);
-    hipLaunchKernelGGL(csc::k_bvh_depth, gn, blk, 0, ctx->stream, b);
-    hipLaunchKernelGGL(csc::k_bvh_level_off, dim3(nchunks), dim3(64), 0, ctx->stream, b);
+    KT("k_bvh_run_start", hipLaunchKernelGGL(csc::k_bvh_run_start, gp, blk, 0, ctx->stream, b));
+    KT("k_bvh_karras", hipLaunchKernelGGL(csc::k_bvh_karras, gp, blk, 0, ctx->stream, b));
+    KT("k_bvh_depth", hipLaunchKernelGGL(csc::k_bvh_depth, gn, blk, 0, ctx->stream, b));
+    KT("k_bvh_level_off", hipLaunchKernelGGL(csc::k_bvh_level_off, dim3(nchunks), dim3(64), 0, ctx->stream, b));
     CSC_LAUNCH_CHECK();
     uint64_t *kres;
     uint32_t *vres;
@@ -673,12 +763,12 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
                                   b.sval_b, &kres, &vres)) {
         return rc;
     }
-    hipLaunchKernelGGL(csc::k_bvh_newidx, gn, blk, 0, ctx->stream, b, vres);
-    hipLaunchKernelGGL(csc::k_bvh_emit, gn, blk, 0, ctx->stream, b, vres);
+    KT("k_bvh_newidx", hipLaunchKernelGGL(csc::k_bvh_newidx, gn, blk, 0, ctx->stream, b, vres));
+    KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit, gn, blk, 0, ctx->stream, b, vres));
     // Bottom-up refit, one launch per level (children are final when their level is done).
     const unsigned rg = std::min(cdiv(nn_max, 256), 1024u);
     for (int level = csc::BVH_MAX_LEVELS - 2; level >= 0; --level) {
-        hipLaunchKernelGGL(csc::k_bvh_refit_level, dim3(rg, nchunks), blk, 0, ctx->stream, b, level);
+        KT("k_bvh_refit_level", hipLaunchKernelGGL(csc::k_bvh_refit_level, dim3(rg, nchunks), blk, 0, ctx->stream, b, level));
     }
     CSC_LAUNCH_CHECK();
     ctx->bvh = b;
@@ -700,8 +790,8 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
         return CSC_ERR_OVERFLOW;
     }
     static_assert(sizeof(csc_bvh_node) == sizeof(csc::bvh_node_ref), "node layout");
-    hipLaunchKernelGGL(csc::k_bvh_export, dim3(cdiv(nn, 256)), dim3(256), 0, ctx->stream, ctx->bvh, chunk,
-                       reinterpret_cast<csc::bvh_node_ref *>(d_nodes));
+    KT("k_bvh_export", hipLaunchKernelGGL(csc::k_bvh_export, dim3(cdiv(nn, 256)), dim3(256), 0, ctx->stream, ctx->bvh, chunk,
+                       reinterpret_cast<csc::bvh_node_ref *>(d_nodes)));
     CSC_LAUNCH_CHECK();
     CSC_HIP(hipStreamSynchronize(ctx->stream));
     return CSC_OK;
@@ -732,7 +822,7 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     q.active = d_active;
     q.count = d_cnt;
     const dim3 grid(cdiv(n, csc::BP_BLOCK), nchunks), blk(csc::BP_BLOCK);
-    hipLaunchKernelGGL((csc::k_broad_phase<false>), grid, blk, 0, ctx->stream, q);
+    KT("k_broad_phase_count", hipLaunchKernelGGL((csc::k_broad_phase<false>), grid, blk, 0, ctx->stream, q));
     CSC_LAUNCH_CHECK();
     const uint64_t ntot = static_cast<uint64_t>(nchunks) * n;
     if (const int rc = scan_impl(ctx, d_cnt, ntot, 1, d_off, nullptr)) {
@@ -750,7 +840,7 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     if (total) {
         q.offset = d_off;
         q.pairs = d_pairs;
-        hipLaunchKernelGGL((csc::k_broad_phase<true>), grid, blk, 0, ctx->stream, q);
+        KT("k_broad_phase_write", hipLaunchKernelGGL((csc::k_broad_phase<true>), grid, blk, 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
     }
     ctx->bp_total = total;
@@ -829,7 +919,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.coll_cap = coll_cap;
         q.conj_cap = conj_cap;
         q.counters = d_cnt;
-        hipLaunchKernelGGL((csc::k_narrow_phase<20>), dim3(cdiv(npairs, 64)), dim3(64), 0, ctx->stream, q);
+        KT("k_narrow_phase", hipLaunchKernelGGL((csc::k_narrow_phase<20>), dim3(cdiv(npairs, 64)), dim3(64), 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
@@ -918,15 +1008,15 @@ int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, cons
         ctx->err = "only Taylor order 20 is built";
         return CSC_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((csc::k_dense<20>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, t, d_tc_off, d_tcs,
-                       d_tcoords, d_out, ctx->d_flags + 1);
+    KT("k_dense", hipLaunchKernelGGL((csc::k_dense<20>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, t, d_tc_off, d_tcs,
+                       d_tcoords, d_out, ctx->d_flags + 1));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
 
 int csc_copy_final_state(csc_ctx *ctx, uint32_t n, const double *d_final_state, double *d_state)
 {
-    hipLaunchKernelGGL(k_copy_final_state, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_final_state, d_state);
+    KT("k_copy_final_state", hipLaunchKernelGGL(k_copy_final_state, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_final_state, d_state));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -953,8 +1043,8 @@ int csc_activity_flags(csc_ctx *ctx, uint32_t n, const double *d_state, double m
         CSC_HIP(hipStreamSynchronize(ctx->stream));
         d_mask = d_m;
     }
-    hipLaunchKernelGGL(k_activity, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_state, min_coll_radius,
-                       with_conj, n_coll_wl == 0 ? 1 : 0, n_conj_wl == 0 ? 1 : 0, d_mask, d_active);
+    KT("k_activity", hipLaunchKernelGGL(k_activity, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_state, min_coll_radius,
+                       with_conj, n_coll_wl == 0 ? 1 : 0, n_conj_wl == 0 ? 1 : 0, d_mask, d_active));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }

@@ -127,6 +127,14 @@ int csc_sync(csc_ctx *ctx);
 int csc_timer_begin(csc_ctx *ctx);
 int csc_timer_end(csc_ctx *ctx, float *ms);
 
+/* Per-kernel timing with HIP events recorded on the context's stream around every kernel
+ * launch (no counterpart in the reference, whose stages log spdlog stopwatches:
+ * src/sim_propagate.cpp:510,1123,1340). csc_profile_get synchronises and writes one line per
+ * kernel, "name launches total_ms", into buf. */
+int csc_profile_enable(csc_ctx *ctx, int on);
+int csc_profile_reset(csc_ctx *ctx);
+int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap);
+
 /* ---- K1/K2: propagation + AABBs -----------------------------------------------------
  * Replaces batch_int_aabb / scalar_int_aabb (src/sim_propagate.cpp:650-1098), the
  * propagate callback (:710-755), compute_particle_aabb (:217-395) and heyoka's

@@ -226,7 +226,7 @@ def test_narrow_phase_injected(orc, ctx, n, n_par_ct, conj):
     """K7 on the oracle's Taylor coefficients and the oracle's broad-phase pairs: collision and
     conjunction sets equal, times/distances/states within 1e-9 relative."""
     st = _pop(n, seed=11)
-    st[:, 6] *= 2000.0  # bigger objects -> some collisions in one superstep
+    st[:, 6] *= 3e4  # bigger objects -> some collisions in one superstep
     s = orc.Sim(st, 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
     s.time = 1.5
     oc = s.step()
@@ -261,7 +261,7 @@ def test_narrow_phase_injected(orc, ctx, n, n_par_ct, conj):
     assert np.array_equal(cj_["i"], oconj["i"]) and np.array_equal(cj_["j"], oconj["j"])
     assert _rel_close(cj_["time"], oconj["time"]) and _rel_close(cj_["state_i"], oconj["state_i"]) and _rel_close(cj_["state_j"], oconj["state_j"])
     assert np.all(np.abs(cj_["dist"] - oconj["dist"]) <= 1e-9)
-    if n_par_ct == 1 and conj == 0.0:
+    if True:
         assert len(ocoll) > 0, "test population should produce collisions"
 
 
