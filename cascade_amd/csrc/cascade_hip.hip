@@ -748,6 +748,8 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     BB(n_nodes, uint32_t, nchunks)
 #undef BB
     const dim3 gp(cdiv(n, 256), nchunks), gn(cdiv(nn_max, 256), nchunks), blk(256);
+    // Per-level node counters start from zero (hipMemsetAsync on the same stream).
+    CSC_HIP(hipMemsetAsync(b.level_cnt, 0, static_cast<size_t>(nchunks) * csc::BVH_MAX_LEVELS * sizeof(uint32_t), ctx->stream));
     KT("k_bvh_heads", hipLaunchKernelGGL(csc::k_bvh_heads, gp, blk, 0, ctx->stream, b));
     if (const int rc = scan_impl(ctx, b.head, n, nchunks, nullptr, b.excl)) {
         return rc;

@@ -552,7 +552,7 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
 // polynomials per thread (42 KB). Here a lane keeps no work-list at all: because the
 // list is LIFO and the right half is pushed last, the pending set is exactly "the left
 // siblings of the right-turns on the current path", so the traversal is driven by a
-// 256-bit path word; a pending left sibling's polynomial is rebuilt by replaying the
+// path word (one bit per level); a pending left sibling's polynomial is rebuilt by replaying the
 // same rescale/translate sequence from the root polynomial, which reproduces the
 // reference's arithmetic operation for operation.
 //
@@ -562,11 +562,16 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
 // appended (as in the reference, :329-336 precede the failure check :373-381);
 // n_lb_roots counts those.
 // ---------------------------------------------------------------------------
+constexpr int RF_PATH_WORDS = 18;                  // 1152 bits
+constexpr int RF_MAX_DEPTH = RF_PATH_WORDS * 64 - 8; // deeper than any interval a double can halve to
+
 struct rf_path {
-    unsigned long long w[4];
+    unsigned long long w[RF_PATH_WORDS];
     __device__ void clear()
     {
-        w[0] = w[1] = w[2] = w[3] = 0;
+        for (int i = 0; i < RF_PATH_WORDS; ++i) {
+            w[i] = 0;
+        }
     }
     __device__ bool get(int i) const
     {
@@ -652,7 +657,10 @@ __device__ inline int isolate_and_refine(const double *poly, int order, double r
             descend = true;
             n_pending += 2;
         }
-        if (n_pending > 250 || n_isol > order) {
+        // NOTE: the depth guard has no counterpart in the reference (whose work-list holds the
+        // polynomials themselves); it only bounds the path word and cannot trigger before an
+        // interval has been halved ~1100 times, i.e. far past double precision.
+        if (n_pending > 250 || n_isol > order || depth >= RF_MAX_DEPTH) {
             *warn |= 4;
             loop_failed = true;
             break;

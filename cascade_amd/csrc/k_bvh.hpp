@@ -68,9 +68,6 @@ __global__ __launch_bounds__(256) void k_bvh_heads(bvh_bufs b)
     }
     const std::uint64_t *codes = b.codes + static_cast<std::size_t>(c) * b.n;
     b.head[static_cast<std::size_t>(c) * b.n + i] = (i == 0 || codes[i] != codes[i - 1]) ? 1u : 0u;
-    if (i < BVH_MAX_LEVELS) {
-        b.level_cnt[c * BVH_MAX_LEVELS + i] = 0;
-    }
 }
 
 __global__ __launch_bounds__(256) void k_bvh_run_start(bvh_bufs b)

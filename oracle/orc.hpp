@@ -619,7 +619,7 @@ inline std::tuple<double, int> bracketed_root_find(const double *poly, std::uint
 }
 
 struct rf_stats {
-    std::uint64_t n_fex_pass = 0, n_fex_fail = 0, n_warn = 0;
+    std::uint64_t n_fex_pass = 0, n_fex_fail = 0, n_warn = 0, max_depth = 0, max_wlist = 0;
 };
 
 // Scratch for real-root isolation (replaces np_data::pwrap / wlist / isol,
@@ -628,6 +628,7 @@ struct rf_scratch {
     struct witem {
         double lb, ub;
         std::vector<double> p;
+        std::uint32_t depth = 0;
     };
     std::vector<witem> wlist;
     std::vector<std::pair<double, double>> isol;
@@ -678,13 +679,15 @@ inline void run_poly_root_finding(const double *poly, std::uint32_t order, doubl
     };
 
     poly_rescale(sc.tmp.data(), poly, rf_int, order);
-    sc.wlist.push_back({0., 1., sc.tmp});
+    sc.wlist.push_back({0., 1., sc.tmp, 0u});
 
     bool loop_failed = false;
 
     do {
         const double lb = sc.wlist.back().lb;
         const double ub = sc.wlist.back().ub;
+        const std::uint32_t depth = sc.wlist.back().depth;
+        stats.max_depth = std::max<std::uint64_t>(stats.max_depth, depth);
         sc.tmp = std::move(sc.wlist.back().p);
         sc.wlist.pop_back();
 
@@ -702,8 +705,9 @@ inline void run_poly_root_finding(const double *poly, std::uint32_t order, doubl
             poly_rescale_p2(sc.tmp1.data(), sc.tmp.data(), order);
             poly_translate_1(sc.tmp2.data(), sc.tmp1.data(), order);
             const double mid = (lb + ub) / 2;
-            sc.wlist.push_back({lb, mid, sc.tmp1});
-            sc.wlist.push_back({mid, ub, sc.tmp2});
+            sc.wlist.push_back({lb, mid, sc.tmp1, depth + 1u});
+            sc.wlist.push_back({mid, ub, sc.tmp2, depth + 1u});
+            stats.max_wlist = std::max<std::uint64_t>(stats.max_wlist, sc.wlist.size());
         }
 
         if (sc.wlist.size() > 250u || sc.isol.size() > order) {

@@ -505,3 +505,16 @@ double orc_rhofac(std::uint32_t p)
     return orc::rhofac(p);
 }
 }
+
+extern "C" {
+// out[5]: max bisection depth, max work-list size, warnings, fex failures, fex passes (cumulative)
+void orc_sim_rf_stats(void *h, std::uint64_t *out)
+{
+    auto *s = static_cast<orc::sim *>(h);
+    out[0] = s->rf_max_depth;
+    out[1] = s->rf_max_wlist;
+    out[2] = s->rf_warn;
+    out[3] = s->rf_fex_fail;
+    out[4] = s->rf_fex_pass;
+}
+}

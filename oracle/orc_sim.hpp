@@ -67,6 +67,7 @@ public:
     std::vector<std::tuple<size_type, double, std::uint32_t>> ste_vec;
     std::vector<std::tuple<size_type, double>> err_nf_state_vec;
     stage_times times;
+    std::uint64_t rf_max_depth = 0, rf_max_wlist = 0, rf_warn = 0, rf_fex_fail = 0, rf_fex_pass = 0;
     bool keep_stage_data = true;
 
     size_type get_nparts() const
@@ -362,6 +363,11 @@ public:
                 }
 #pragma omp critical
                 {
+                    rf_max_depth = std::max(rf_max_depth, sc.st.max_depth);
+                    rf_max_wlist = std::max(rf_max_wlist, sc.st.max_wlist);
+                    rf_warn += sc.st.n_warn;
+                    rf_fex_fail += sc.st.n_fex_fail;
+                    rf_fex_pass += sc.st.n_fex_pass;
                     coll_vec.insert(coll_vec.end(), loc_coll.begin(), loc_coll.end());
                     conj_vecs[c].insert(conj_vecs[c].end(), loc_conj.begin(), loc_conj.end());
                 }

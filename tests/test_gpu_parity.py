@@ -51,7 +51,7 @@ def _oracle_step(orc, st, n_par_ct, **kw):
     return s, oc
 
 
-@pytest.mark.parametrize("n,n_par_ct,same_code", [(2, 1, False), (6, 3, False), (64, 1, False), (2003, 1, False), (2003, 3, False), (2003, 3, True), (20000, 2, False)])
+@pytest.mark.parametrize("n,n_par_ct,same_code", [(2, 1, False), (6, 3, False), (64, 1, False), (2003, 1, False), (2003, 3, False), (2003, 3, True), (20000, 2, False), (4, 2, False), (3, 1, False), (70, 3, False)])
 def test_aabb_to_pairs_bit_exact(orc, ctx, n, n_par_ct, same_code):
     """K2b-K6 on injected (oracle) AABBs: global AABB, Morton codes, stable permutation,
     sorted arrays, BVH nodes and broad-phase pairs are bit-identical."""
