@@ -47,10 +47,11 @@ struct csc_ctx {
     // BVH state of the last csc_bvh_build
     csc::bvh_bufs bvh{};
     uint32_t bvh_n = 0, bvh_chunks = 0;
+    bool bvh_packed = false; // wide traversal nodes built for the current trees
     // broad phase state
-    uint64_t bp_total = 0;
+    uint64_t bp_total = 0, bp_cap = 0;
     uint32_t bp_n = 0, bp_chunks = 0;
-    std::vector<uint64_t> bp_chunk_off;
+    unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
     std::vector<csc_conjunction> conj;
@@ -277,6 +278,29 @@ __global__ __launch_bounds__(256) void k_activity(uint32_t n, const double *stat
     active[i] = static_cast<uint8_t>((coll ? 1u : 0u) | (conj ? 2u : 0u));
 }
 
+__global__ __launch_bounds__(256) void k_gather_u32(uint32_t n, const uint32_t *in, const uint32_t *idx, uint32_t *out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        out[k] = in[idx ? idx[k] : k];
+    }
+}
+
+// Caller-provided [npairs][2] pairs with per-chunk offsets -> {i, j, chunk, 0} records.
+__global__ __launch_bounds__(256) void k_tag_pairs(uint64_t npairs, const uint32_t *pairs, const uint64_t *off,
+                                                   uint32_t nchunks, uint4 *out)
+{
+    const uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= npairs) {
+        return;
+    }
+    uint32_t c = 0;
+    while (c + 1u < nchunks && off[c + 1u] <= k) {
+        ++c;
+    }
+    out[k] = make_uint4(pairs[k * 2u], pairs[k * 2u + 1u], c, 0u);
+}
+
 csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const double *d_state)
 {
     csc::prop_params p{};
@@ -322,6 +346,9 @@ int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
 
 } // namespace
 
+static int scan_impl(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint32_t nseg, uint64_t *d_out64,
+                     uint32_t *d_out32);
+
 extern "C" {
 
 int csc_ctx_create(int device, csc_ctx **out)
@@ -354,6 +381,8 @@ int csc_ctx_create(int device, csc_ctx **out)
         delete ctx;
         return CSC_ERR_HIP;
     }
+    // [0..1] error flags (int), broad-phase pair counter: u64 at byte offset 64.
+    ctx->d_bp_counter = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->d_flags) + 64);
     *out = ctx;
     return CSC_OK;
 }
@@ -531,15 +560,33 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
     return CSC_OK;
 }
 
+int csc_tc_strides(uint32_t order, uint32_t *xyz_stride, uint32_t *vr_stride)
+{
+    *xyz_stride = static_cast<uint32_t>(csc::tc_xyz_stride(static_cast<int>(order)));
+    *vr_stride = static_cast<uint32_t>(csc::tc_vr_stride(static_cast<int>(order)));
+    return CSC_OK;
+}
+
 int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state,
-                        const uint64_t *d_tc_off, double *d_tcs, double *d_tcoords)
+                        const uint32_t *d_order, const uint32_t *d_nsub, uint64_t *d_tc_row, double *d_tcs_xyz,
+                        double *d_tcs_vr, double *d_tcoords)
 {
     if (const int rc = check_cfg(ctx, cfg)) {
         return rc;
     }
+    // Row starts in lane (= Morton) order: exclusive scan of nsub[order[k]].
+    CSC_BUF(d_ns, uint32_t, "tc_nsub_ordered", n);
+    CSC_BUF(d_base, uint64_t, "tc_row_base", n + 1u);
+    KT("k_gather_u32", hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_nsub, d_order, d_ns));
+    if (const int rc = scan_impl(ctx, d_ns, n, 1, d_base, nullptr)) {
+        return rc;
+    }
     csc::prop_params p = make_prop_params(cfg, n, d_state);
-    p.tc_off = d_tc_off;
-    p.tcs = d_tcs;
+    p.order = d_order;
+    p.row_base = d_base;
+    p.tc_row = d_tc_row;
+    p.tcs_xyz = d_tcs_xyz;
+    p.tcs_vr = d_tcs_vr;
     p.tcoords = d_tcoords;
     const bool events = cfg->has_exit || cfg->has_reentry;
     const dim3 grid(cdiv(n, 64)), block(64);
@@ -747,6 +794,7 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     BB(nsplit, int32_t, cnn)
     BB(n_nodes, uint32_t, nchunks)
 #undef BB
+    CSC_BUF(d_tn, csc::tnode, "bvh_tnodes", cnn);
     const dim3 gp(cdiv(n, 256), nchunks), gn(cdiv(nn_max, 256), nchunks), blk(256);
     // Per-level node counters start from zero (hipMemsetAsync on the same stream).
     CSC_HIP(hipMemsetAsync(b.level_cnt, 0, static_cast<size_t>(nchunks) * csc::BVH_MAX_LEVELS * sizeof(uint32_t), ctx->stream));
@@ -774,6 +822,7 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     }
     CSC_LAUNCH_CHECK();
     ctx->bvh = b;
+    ctx->bvh_packed = false;
     ctx->bvh_n = n;
     ctx->bvh_chunks = nchunks;
     return CSC_OK;
@@ -807,48 +856,83 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     if (n != ctx->bvh_n || nchunks > ctx->bvh_chunks) {
         return ctx->invalid("broad phase does not match the last BVH build");
     }
-    const size_t cn = static_cast<size_t>(ctx->bvh_chunks) * n;
-    CSC_BUF(d_cnt, uint32_t, "bp_count", cn);
-    CSC_BUF(d_off, uint64_t, "bp_offset", cn + 1u);
+    const size_t cnn = static_cast<size_t>(ctx->bvh_chunks) * ctx->bvh.nn_max;
+    CSC_BUF(d_tn, csc::tnode, "bvh_tnodes", cnn);
+    if (!ctx->bvh_packed) {
+        // Wide traversal nodes (needs the Morton permutation for the leaf descriptors).
+        KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
+                                             ctx->stream, ctx->bvh, d_vidx, d_tn));
+        CSC_LAUNCH_CHECK();
+        ctx->bvh_packed = true;
+    }
     csc::bp_params q{};
     q.n = n;
     q.nn_max = ctx->bvh.nn_max;
     q.slb = reinterpret_cast<const float4 *>(d_srt_lbs);
     q.sub = reinterpret_cast<const float4 *>(d_srt_ubs);
     q.vidx = d_vidx;
+    q.tn = d_tn;
     q.nlb = ctx->bvh.nlb;
     q.nub = ctx->bvh.nub;
     q.nleft = ctx->bvh.nleft;
-    q.nb = ctx->bvh.nb;
-    q.ne = ctx->bvh.ne;
     q.active = d_active;
-    q.count = d_cnt;
+    q.counter = ctx->d_bp_counter;
     const dim3 grid(cdiv(n, csc::BP_BLOCK), nchunks), blk(csc::BP_BLOCK);
-    KT("k_broad_phase_count", hipLaunchKernelGGL((csc::k_broad_phase<false>), grid, blk, 0, ctx->stream, q));
-    CSC_LAUNCH_CHECK();
-    const uint64_t ntot = static_cast<uint64_t>(nchunks) * n;
-    if (const int rc = scan_impl(ctx, d_cnt, ntot, 1, d_off, nullptr)) {
-        return rc;
-    }
-    // Per-chunk starts + total.
-    ctx->bp_chunk_off.assign(nchunks + 1u, 0);
-    for (uint32_t c = 0; c <= nchunks; ++c) {
-        CSC_HIP(hipMemcpyAsync(&ctx->bp_chunk_off[c], d_off + static_cast<uint64_t>(c) * n, sizeof(uint64_t),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    }
-    CSC_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t total = ctx->bp_chunk_off[nchunks];
-    CSC_BUF(d_pairs, uint32_t, "bp_pairs", std::max<uint64_t>(total, 1) * 2u);
-    if (total) {
-        q.offset = d_off;
+    // The pair list is appended through a device counter; its capacity follows the last
+    // superstep's count (populations change slowly), and an overflow re-runs the traversal.
+    uint64_t cap = std::max<uint64_t>({ctx->bp_cap, static_cast<uint64_t>(n) * nchunks * 8u, 1u << 16});
+    unsigned long long total = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        CSC_BUF(d_pairs, uint4, "bp_pairs", cap);
         q.pairs = d_pairs;
-        KT("k_broad_phase_write", hipLaunchKernelGGL((csc::k_broad_phase<true>), grid, blk, 0, ctx->stream, q));
+        q.cap = cap;
+        CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, sizeof(unsigned long long), ctx->stream));
+        KT("k_broad_phase", hipLaunchKernelGGL((csc::k_broad_phase<false>), grid, blk, 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
+        CSC_HIP(hipMemcpyAsync(&total, ctx->d_bp_counter, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        if (total <= cap) {
+            break;
+        }
+        cap = total + total / 8u;
     }
+    if (total > cap) {
+        ctx->err = "broad phase pair list overflow";
+        return CSC_ERR_OVERFLOW;
+    }
+    ctx->bp_cap = std::max<uint64_t>(cap, total + total / 4u);
     ctx->bp_total = total;
     ctx->bp_n = n;
     ctx->bp_chunks = nchunks;
     *n_pairs = total;
+    return CSC_OK;
+}
+
+int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                          const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *nodes_visited)
+{
+    if (n != ctx->bp_n || nchunks > ctx->bp_chunks || !ctx->bvh_packed) {
+        return ctx->invalid("broad phase statistics need a preceding csc_broad_phase on the same trees");
+    }
+    csc::bp_params q{};
+    q.n = n;
+    q.nn_max = ctx->bvh.nn_max;
+    q.slb = reinterpret_cast<const float4 *>(d_srt_lbs);
+    q.sub = reinterpret_cast<const float4 *>(d_srt_ubs);
+    q.vidx = d_vidx;
+    q.tn = static_cast<const csc::tnode *>(ctx->bufs["bvh_tnodes"].p);
+    q.nlb = ctx->bvh.nlb;
+    q.nub = ctx->bvh.nub;
+    q.nleft = ctx->bvh.nleft;
+    q.active = d_active;
+    q.counter = ctx->d_bp_counter;
+    CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL((csc::k_broad_phase<true>), dim3(cdiv(n, csc::BP_BLOCK), nchunks), dim3(csc::BP_BLOCK), 0, ctx->stream, q);
+    CSC_LAUNCH_CHECK();
+    unsigned long long v = 0;
+    CSC_HIP(hipMemcpyAsync(&v, ctx->d_bp_counter + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    *nodes_visited = v;
     return CSC_OK;
 }
 
@@ -857,15 +941,23 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
     if (chunk >= ctx->bp_chunks) {
         return ctx->invalid("invalid chunk index");
     }
-    const uint64_t b = ctx->bp_chunk_off[chunk], e = ctx->bp_chunk_off[chunk + 1u];
-    *count = e - b;
-    const uint64_t ncopy = std::min(cap, e - b);
-    if (ncopy) {
-        const uint32_t *d_pairs = static_cast<const uint32_t *>(ctx->bufs["bp_pairs"].p);
-        CSC_HIP(hipMemcpyAsync(pairs, d_pairs + b * 2u, ncopy * 2u * sizeof(uint32_t), hipMemcpyDeviceToHost,
+    std::vector<uint4> h(ctx->bp_total);
+    if (ctx->bp_total) {
+        CSC_HIP(hipMemcpyAsync(h.data(), ctx->bufs["bp_pairs"].p, ctx->bp_total * sizeof(uint4), hipMemcpyDeviceToHost,
                                ctx->stream));
     }
     CSC_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t k = 0;
+    for (const auto &r : h) {
+        if (r.z == chunk) {
+            if (k < cap) {
+                pairs[k * 2u] = r.x;
+                pairs[k * 2u + 1u] = r.y;
+            }
+            ++k;
+        }
+    }
+    *count = k;
     return CSC_OK;
 }
 
@@ -873,8 +965,8 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
 
 static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                        double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
-                       const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs, const double *d_tcoords,
-                       const uint32_t *d_pairs, const uint64_t *d_bp_off, uint32_t n0, uint64_t npairs,
+                       const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
+                       const double *d_tcs_vr, const double *d_tcoords, const uint4 *d_pairs, uint64_t npairs,
                        uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
 {
     if (order != 20u) {
@@ -909,12 +1001,12 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.conj_thresh2 = conj_thresh * conj_thresh;
         q.state = d_state;
         q.active = d_active;
-        q.tc_off = d_tc_off;
-        q.tcs = d_tcs;
+        q.tc_row = d_tc_row;
+        q.nsub = d_nsub;
+        q.tcs_xyz = d_tcs_xyz;
+        q.tcs_vr = d_tcs_vr;
         q.tcoords = d_tcoords;
         q.pairs = d_pairs;
-        q.bp_off = d_bp_off;
-        q.n0 = n0;
         q.npairs = npairs;
         q.coll = d_coll;
         q.conj = d_conj;
@@ -961,32 +1053,38 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
 
 int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                      double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
-                     const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs, const double *d_tcoords,
-                     uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
+                     const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
+                     const double *d_tcs_vr, const double *d_tcoords, uint64_t *n_coll, uint64_t *n_conj,
+                     uint32_t *warn_flags)
 {
     if (n != ctx->bp_n || nchunks > ctx->bp_chunks) {
         return ctx->invalid("narrow phase does not match the last broad phase");
     }
-    // After a terminal-event shrink only the pairs of the surviving chunks are processed.
-    const uint64_t npairs = ctx->bp_chunk_off[nchunks];
+    // After a terminal-event shrink the kernel skips the pairs of the dropped chunks.
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
-                       d_tc_off, d_tcs, d_tcoords, static_cast<const uint32_t *>(ctx->bufs["bp_pairs"].p),
-                       static_cast<const uint64_t *>(ctx->bufs["bp_offset"].p), n, npairs, n_coll, n_conj,
-                       warn_flags);
+                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords,
+                       static_cast<const uint4 *>(ctx->bufs["bp_pairs"].p), ctx->bp_total, n_coll, n_conj, warn_flags);
 }
 
 int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                            double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
-                           const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs,
-                           const double *d_tcoords, const uint32_t *d_pairs, const uint64_t *pair_off,
-                           uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
+                           const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub,
+                           const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords,
+                           const uint32_t *d_pairs, const uint64_t *pair_off, uint64_t *n_coll, uint64_t *n_conj,
+                           uint32_t *warn_flags)
 {
-    // Chunk starts with stride 1 (n0 = 1): bp_off[c] = pair_off[c].
+    const uint64_t npairs = pair_off[nchunks];
     CSC_BUF(d_off, uint64_t, "np_pair_off", nchunks + 1u);
+    CSC_BUF(d_rec, uint4, "np_pair_rec", std::max<uint64_t>(npairs, 1));
     CSC_HIP(hipMemcpyAsync(d_off, pair_off, (nchunks + 1u) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     CSC_HIP(hipStreamSynchronize(ctx->stream));
+    if (npairs) {
+        KT("k_tag_pairs", hipLaunchKernelGGL(k_tag_pairs, dim3(cdiv(npairs, 256)), dim3(256), 0, ctx->stream, npairs, d_pairs, d_off,
+                                              nchunks, d_rec));
+        CSC_LAUNCH_CHECK();
+    }
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
-                       d_tc_off, d_tcs, d_tcoords, d_pairs, d_off, 1, pair_off[nchunks], n_coll, n_conj, warn_flags);
+                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, d_rec, npairs, n_coll, n_conj, warn_flags);
 }
 
 int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,
@@ -1003,15 +1101,16 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
 
 // ---- K8 and helpers --------------------------------------------------------------------
 
-int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, const uint64_t *d_tc_off,
-                        const double *d_tcs, const double *d_tcoords, double *d_out)
+int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, const uint64_t *d_tc_row,
+                        const uint32_t *d_nsub, const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords,
+                        double *d_out)
 {
     if (order != 20u) {
         ctx->err = "only Taylor order 20 is built";
         return CSC_ERR_UNSUPPORTED;
     }
-    KT("k_dense", hipLaunchKernelGGL((csc::k_dense<20>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, t, d_tc_off, d_tcs,
-                       d_tcoords, d_out, ctx->d_flags + 1));
+    KT("k_dense", hipLaunchKernelGGL((csc::k_dense<20>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, t, d_tc_row, d_nsub,
+                       d_tcs_xyz, d_tcs_vr, d_tcoords, d_out, ctx->d_flags + 1));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }

@@ -338,31 +338,99 @@ __global__ __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t ch
 }
 
 // ---------------------------------------------------------------------------
-// K6: broad phase. One lane per Morton-ordered particle, explicit DFS stack in LDS,
-// closed-interval overlap on 4 dimensions, pairs (orig_pidx < orig_i) with at least one
-// activity flag. Count pass -> exclusive scan -> write pass (deterministic layout: pairs
-// grouped by query particle in Morton order). Replaces src/sim_broad_phase.cpp:92-202.
-// Traffic: 36 B per visited node (L2-resident tree top, HBM for the deep levels) + 8 B
-// per pair written.
+// K6: broad phase. Replaces src/sim_broad_phase.cpp:92-202.
+//
+// Traversal layout ("wide" nodes): every internal node carries the AABBs and descriptors of
+// BOTH children in one 96-byte record, so one fetch decides two subtrees and a child that
+// does not overlap is never fetched at all. A child descriptor is {left, begin, end, orig}:
+// left = canonical index of the child's own record (-1 for a leaf), [begin, end) its
+// particle range, orig = original index of the first particle (saves the vidx lookup for
+// single-particle leaves). The tests performed are exactly the reference's (closed-interval
+// overlap of the query AABB with the node AABB on 4 dimensions, leaf test against the LEAF
+// NODE box, pairs (orig_pidx < orig_i) with at least one activity flag), only their order
+// differs, so the pair SET is identical.
+//
+// One lane per Morton-ordered particle, DFS stack in LDS, pairs appended to one global list
+// through a device counter (the compiler folds the per-lane atomicAdd(.., 1) into one atomic
+// per wave instruction). A pair record is {i, j, chunk, 0} (16 bytes, one store). The list
+// order is not deterministic; every consumer is order-independent.
+// Traffic: 96 B per visited internal node (L2-resident near the root) + 16 B per pair.
 // ---------------------------------------------------------------------------
 constexpr int BP_BLOCK = 64;
 constexpr int BP_STACK = 72; // depth <= 64 -> at most 65 pending entries
+
+struct tnode {
+    float4 lb0, ub0, lb1, ub1;
+    int4 c0, c1;
+};
+static_assert(sizeof(tnode) == 96, "wide node layout");
+
+// One thread per canonical node; internal nodes fill their record.
+__global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, tnode *tn)
+{
+    const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.n_nodes[c]) {
+        return;
+    }
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
+    const std::int32_t l = b.nleft[no + p];
+    if (l < 0) {
+        return;
+    }
+    const std::uint32_t *vx = vidx + static_cast<std::size_t>(c) * b.n;
+    tnode t;
+    t.lb0 = b.nlb[no + l];
+    t.ub0 = b.nub[no + l];
+    t.lb1 = b.nlb[no + l + 1];
+    t.ub1 = b.nub[no + l + 1];
+    const std::uint32_t b0 = b.nb[no + l], b1 = b.nb[no + l + 1];
+    t.c0 = make_int4(b.nleft[no + l], static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(vx[b0]));
+    t.c1 = make_int4(b.nleft[no + l + 1], static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]),
+                     static_cast<int>(vx[b1]));
+    tn[no + p] = t;
+}
 
 struct bp_params {
     std::uint32_t n;
     std::uint32_t nn_max;
     const float4 *slb, *sub;     // [C][n]
     const std::uint32_t *vidx;   // [C][n]
-    const float4 *nlb, *nub;     // [C][nn_max]
-    const std::int32_t *nleft;
-    const std::uint32_t *nb, *ne;
+    const tnode *tn;             // [C][nn_max]
+    const float4 *nlb, *nub;     // [C][nn_max] (root box)
+    const std::int32_t *nleft;   // root leaf test
     const std::uint8_t *active;  // [n] bit0 coll_active, bit1 conj_active
-    std::uint32_t *count;        // [C][n] (count pass)
-    const std::uint64_t *offset; // [C * n + 1] exclusive scan over all chunks (write pass)
-    std::uint32_t *pairs;        // [total][2]
+    uint4 *pairs;                // [cap] {i, j, chunk, 0}
+    std::uint64_t cap;
+    unsigned long long *counter; // number of pairs found (may exceed cap: overflow)
 };
 
-template <bool WRITE>
+CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, const float4 &nu)
+{
+    return (pub.x >= nl.x && plb.x <= nu.x) && (pub.y >= nl.y && plb.y <= nu.y) && (pub.z >= nl.z && plb.z <= nu.z)
+           && (pub.w >= nl.w && plb.w <= nu.w);
+}
+
+CSC_DEV void bp_emit_leaf(const bp_params &q, std::uint32_t c, std::size_t po, std::uint32_t orig_pidx, bool act_p,
+                          const int4 &cd)
+{
+    const std::uint32_t b = static_cast<std::uint32_t>(cd.y), e = static_cast<std::uint32_t>(cd.z);
+    for (std::uint32_t i = b; i != e; ++i) {
+        const std::uint32_t orig_i = (i == b) ? static_cast<std::uint32_t>(cd.w) : q.vidx[po + i];
+        if (orig_pidx >= orig_i) {
+            continue;
+        }
+        if (act_p || q.active[orig_i] != 0) {
+            const unsigned long long slot = atomicAdd(q.counter, 1ull);
+            if (slot < q.cap) {
+                q.pairs[slot] = make_uint4(orig_pidx, orig_i, c, 0u);
+            }
+        }
+    }
+}
+
+// STATS = true: diagnostic variant, writes nothing and adds the number of node AABB tests
+// (the reference's "nodes visited": every node popped from its stack) to counter[1].
+template <bool STATS>
 __global__ __launch_bounds__(BP_BLOCK) void k_broad_phase(bp_params q)
 {
     __shared__ std::int32_t stack[BP_STACK][BP_BLOCK];
@@ -377,44 +445,59 @@ __global__ __launch_bounds__(BP_BLOCK) void k_broad_phase(bp_params q)
     const std::uint32_t orig_pidx = q.vidx[po + pidx];
     const bool act_p = q.active[orig_pidx] != 0;
     const float4 plb = q.slb[po + pidx], pub = q.sub[po + pidx];
-    std::uint32_t cnt = 0;
-    std::uint64_t wpos = 0;
-    if constexpr (WRITE) {
-        wpos = q.offset[po + pidx];
+    // Root.
+    if (!bp_overlap(plb, pub, q.nlb[no], q.nub[no])) {
+        return;
+    }
+    if constexpr (STATS) {
+        if (q.nleft[no] < 0) {
+            atomicAdd(q.counter + 1, 1ull);
+            return;
+        }
+        unsigned long long visits = 1;
+        int sp = 0;
+        stack[sp++][tid] = 0;
+        do {
+            const std::int32_t node = stack[--sp][tid];
+            const tnode *t = q.tn + no + node;
+            visits += 2;
+            if (bp_overlap(plb, pub, t->lb0, t->ub0) && t->c0.x >= 0) {
+                stack[sp++][tid] = t->c0.x;
+            }
+            if (bp_overlap(plb, pub, t->lb1, t->ub1) && t->c1.x >= 0) {
+                stack[sp++][tid] = t->c1.x;
+            }
+        } while (sp > 0);
+        atomicAdd(q.counter + 1, visits);
+        return;
+    }
+    if (q.nleft[no] < 0) {
+        // The tree is a single (multi-particle) leaf.
+        bp_emit_leaf(q, c, po, orig_pidx, act_p, make_int4(-1, 0, static_cast<int>(q.n), static_cast<int>(q.vidx[po])));
+        return;
     }
     int sp = 0;
     stack[sp++][tid] = 0;
     do {
         const std::int32_t node = stack[--sp][tid];
-        const float4 nl = q.nlb[no + node], nu = q.nub[no + node];
-        const bool overlap = (pub.x >= nl.x && plb.x <= nu.x) && (pub.y >= nl.y && plb.y <= nu.y)
-                             && (pub.z >= nl.z && plb.z <= nu.z) && (pub.w >= nl.w && plb.w <= nu.w);
-        if (overlap) {
-            const std::int32_t left = q.nleft[no + node];
-            if (left == -1) {
-                const std::uint32_t b = q.nb[no + node], e = q.ne[no + node];
-                for (std::uint32_t i = b; i != e; ++i) {
-                    const std::uint32_t orig_i = q.vidx[po + i];
-                    if (orig_pidx >= orig_i) {
-                        continue;
-                    }
-                    if (act_p || q.active[orig_i] != 0) {
-                        if constexpr (WRITE) {
-                            q.pairs[(wpos + cnt) * 2u] = orig_pidx;
-                            q.pairs[(wpos + cnt) * 2u + 1u] = orig_i;
-                        }
-                        ++cnt;
-                    }
-                }
+        const tnode *t = q.tn + no + node;
+        const float4 lb0 = t->lb0, ub0 = t->ub0, lb1 = t->lb1, ub1 = t->ub1;
+        const int4 c0 = t->c0, c1 = t->c1;
+        if (bp_overlap(plb, pub, lb0, ub0)) {
+            if (c0.x < 0) {
+                bp_emit_leaf(q, c, po, orig_pidx, act_p, c0);
             } else {
-                stack[sp++][tid] = left;
-                stack[sp++][tid] = left + 1;
+                stack[sp++][tid] = c0.x;
+            }
+        }
+        if (bp_overlap(plb, pub, lb1, ub1)) {
+            if (c1.x < 0) {
+                bp_emit_leaf(q, c, po, orig_pidx, act_p, c1);
+            } else {
+                stack[sp++][tid] = c1.x;
             }
         }
     } while (sp > 0);
-    if constexpr (!WRITE) {
-        q.count[po + pidx] = cnt;
-    }
 }
 
 } // namespace csc

@@ -11,11 +11,14 @@
 //   src/sim_narrow_phase.cpp:208-422   run_poly_root_finding (slow path in dev_math.hpp)
 //   src/sim_jit.cpp:64-113, 118-218    pta_cfunc / ssdiff3_cfunc (register versions here)
 //   src/sim_propagate.cpp:1386-1503    dense_propagate
-// Traffic per pair-interval: 2 x 504 B of Taylor coefficients (2 x 1008 B with conjunction
-// tracking survivors), 2 x 16 B substep times, 8 B pair; ~1.5 kFLOP. HBM/L2 bound.
+// Traffic per pair-interval: 2 x 512 B of x/y/z Taylor coefficients (4 aligned cache lines
+// each; the vx/vy/vz/r rows are only read for recorded conjunctions), 2 x 16 B substep
+// times, 16 B pair record; ~1.5 kFLOP. L2/HBM bound: rows are stored in Morton order, so the
+// rows gathered by one wave (64 pairs of neighbouring queries) are neighbours in memory.
 #pragma once
 
 #include "dev_math.hpp"
+#include "k_propagate.hpp"
 
 namespace csc
 {
@@ -41,12 +44,12 @@ struct np_params {
     double conj_thresh2;
     const double *state;          // [n][7] (sizes)
     const std::uint8_t *active;   // [n] bit0 coll, bit1 conj
-    const std::uint64_t *tc_off;  // [n + 1]
-    const double *tcs;            // CSR rows of 7 * (P + 1)
+    const std::uint64_t *tc_row;  // [n] first CSR row of particle i
+    const std::uint32_t *nsub;    // [n] number of rows of particle i
+    const double *tcs_xyz;        // CSR rows of tc_xyz_stride(P)
+    const double *tcs_vr;         // CSR rows of tc_vr_stride(P)
     const double *tcoords;        // CSR rows of 2
-    const std::uint32_t *pairs;   // [npairs][2]
-    const std::uint64_t *bp_off;  // [C * n0 + 1] broad-phase offsets (chunk c starts at bp_off[c * n0])
-    std::uint32_t n0;             // stride of bp_off per chunk (== n)
+    const uint4 *pairs;           // [npairs] {i, j, chunk, 0}
     std::uint64_t npairs;
     coll_rec *coll;
     conj_rec *conj;
@@ -150,15 +153,19 @@ struct sq_all {
     }
 };
 
-// Loads coordinate c of row `row`, translated by delta when delta != 0.
+// Loads coordinate c (0..2) of row `row`, translated by delta when delta != 0. The row is
+// 16-byte aligned: 128-bit loads, indices resolved at compile time once c is unrolled.
 template <int P>
-CSC_DEV void load_poly(double *out, const double *tcs, std::uint64_t row, int c, double delta)
+CSC_DEV void load_poly(double *out, const double *xyz, std::uint64_t row, int c, double delta)
 {
-    const double *src = tcs + row * static_cast<std::uint64_t>(7 * (P + 1)) + c * (P + 1);
+    const double2 *src = reinterpret_cast<const double2 *>(xyz + row * static_cast<std::uint64_t>(tc_xyz_stride(P)));
     double tmp[P + 1];
+    const int e0 = c * (P + 1);
 #pragma unroll
     for (int o = 0; o <= P; ++o) {
-        tmp[o] = src[o];
+        const int e = e0 + o;
+        const double2 v = src[e >> 1];
+        tmp[o] = (e & 1) ? v.y : v.x;
     }
     if (delta != 0.) {
         translate_a_regs<P>(out, tmp, delta);
@@ -170,10 +177,12 @@ CSC_DEV void load_poly(double *out, const double *tcs, std::uint64_t row, int c,
     }
 }
 
-// Runtime-order copy of the same load (slow path; private memory).
-__device__ inline void load_poly_rt(double *out, const double *tcs, std::uint64_t row, int c, double delta, int P)
+// Runtime-order load of any of the 6 coordinates (slow path; private memory).
+__device__ inline void load_poly_rt(double *out, const double *xyz, const double *vr, std::uint64_t row, int c,
+                                    double delta, int P)
 {
-    const double *src = tcs + row * static_cast<std::uint64_t>(7 * (P + 1)) + c * (P + 1);
+    const double *src = (c < 3) ? xyz + row * static_cast<std::uint64_t>(tc_xyz_stride(P)) + c * (P + 1)
+                                : vr + row * static_cast<std::uint64_t>(tc_vr_stride(P)) + (c - 3) * (P + 1);
     if (delta != 0.) {
         double tmp[RF_MAX_ORDER + 1];
         for (int o = 0; o <= P; ++o) {
@@ -250,9 +259,9 @@ CSC_DEV_NOINLINE void np_slow_path(const np_params &q, const double *ss_in, bool
                 c.dist = sqrt(dmax(conj_dist2, 0.));
                 double poly[P + 1];
                 for (int cc = 0; cc < 6; ++cc) {
-                    load_poly_rt(poly, q.tcs, row_i, cc, delta_i, P);
+                    load_poly_rt(poly, q.tcs_xyz, q.tcs_vr, row_i, cc, delta_i, P);
                     c.state_i[cc] = poly_eval(poly, conj_tm, P);
-                    load_poly_rt(poly, q.tcs, row_j, cc, delta_j, P);
+                    load_poly_rt(poly, q.tcs_xyz, q.tcs_vr, row_j, cc, delta_j, P);
                     c.state_j[cc] = poly_eval(poly, conj_tm, P);
                 }
                 const std::uint32_t slot = atomicAdd(&q.counters[1], 1u);
@@ -274,21 +283,12 @@ __global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
     if (k >= q.npairs) {
         return;
     }
-    // Chunk of this pair: last c with bp_off[c * n0] <= k.
-    std::uint32_t c = 0;
-    {
-        std::uint32_t lo = 0, hi = q.nchunks; // invariant: start(lo) <= k < start(hi) (start(nchunks) = npairs)
-        while (hi - lo > 1) {
-            const std::uint32_t mid = (lo + hi) / 2;
-            if (q.bp_off[static_cast<std::uint64_t>(mid) * q.n0] <= k) {
-                lo = mid;
-            } else {
-                hi = mid;
-            }
-        }
-        c = lo;
+    const uint4 rec = q.pairs[k];
+    const std::uint32_t pi = rec.x, pj = rec.y, c = rec.z;
+    if (c >= q.nchunks) {
+        // Chunk dropped by a terminal-event shrink of the superstep (src/sim_narrow_phase.cpp:560).
+        return;
     }
-    const std::uint32_t pi = q.pairs[k * 2u], pj = q.pairs[k * 2u + 1u];
     const std::uint8_t ai = q.active[pi], aj = q.active[pj];
     const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
     const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
@@ -299,9 +299,8 @@ __global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
     const dfl chunk_begin = df(q.ct * static_cast<double>(c));
     const dfl chunk_end = df((c == q.nchunks - 1u) ? q.delta_t : q.ct * static_cast<double>(c + 1u));
 
-    const std::uint64_t off_i = q.tc_off[pi], off_j = q.tc_off[pj];
-    const std::uint32_t ns_i = static_cast<std::uint32_t>(q.tc_off[pi + 1u] - off_i);
-    const std::uint32_t ns_j = static_cast<std::uint32_t>(q.tc_off[pj + 1u] - off_j);
+    const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
+    const std::uint32_t ns_i = q.nsub[pi], ns_j = q.nsub[pj];
     std::uint32_t it_i, end_i, it_j, end_j;
     substep_range(q.tcoords, off_i, ns_i, chunk_begin, chunk_end, it_i, end_i);
     substep_range(q.tcoords, off_j, ns_j, chunk_begin, chunk_end, it_j, end_j);
@@ -330,8 +329,8 @@ __global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
             double a[P + 1], b[P + 1], d[P + 1], sq[P + 1];
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
-                load_poly<P>(a, q.tcs, off_i + it_i, cc, delta_i);
-                load_poly<P>(b, q.tcs, off_j + it_j, cc, delta_j);
+                load_poly<P>(a, q.tcs_xyz, off_i + it_i, cc, delta_i);
+                load_poly<P>(b, q.tcs_xyz, off_j + it_j, cc, delta_j);
 #pragma unroll
                 for (int o = 0; o <= P; ++o) {
                     d[o] = a[o] - b[o];
@@ -387,15 +386,16 @@ __global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
 
 // K8: dense_propagate (src/sim_propagate.cpp:1401-1500). out: [n][6].
 template <int P>
-__global__ __launch_bounds__(256) void k_dense(std::uint32_t n, double t, const std::uint64_t *tc_off,
-                                               const double *tcs, const double *tcoords, double *out, int *err_flag)
+__global__ __launch_bounds__(256) void k_dense(std::uint32_t n, double t, const std::uint64_t *tc_row,
+                                               const std::uint32_t *nsub, const double *tcs_xyz, const double *tcs_vr,
+                                               const double *tcoords, double *out, int *err_flag)
 {
     const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
         return;
     }
-    const std::uint64_t off = tc_off[i];
-    const std::uint32_t ns = static_cast<std::uint32_t>(tc_off[i + 1u] - off);
+    const std::uint64_t off = tc_row[i];
+    const std::uint32_t ns = nsub[i];
     if (ns == 0u) {
         atomicOr(err_flag, 1);
         return;
@@ -417,10 +417,11 @@ __global__ __launch_bounds__(256) void k_dense(std::uint32_t n, double t, const 
     }
     const dfl ss_start = (lo == 0u) ? df(0.) : load_tcoord(tcoords, off + lo - 1u);
     const double eval_tm = df_sub(dt, ss_start).hi;
-    const double *base = tcs + (off + lo) * static_cast<std::uint64_t>(7 * (P + 1));
+    const double *bxyz = tcs_xyz + (off + lo) * static_cast<std::uint64_t>(tc_xyz_stride(P));
+    const double *bvr = tcs_vr + (off + lo) * static_cast<std::uint64_t>(tc_vr_stride(P));
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        const double *p = base + c * (P + 1);
+        const double *p = (c < 3) ? bxyz + c * (P + 1) : bvr + (c - 3) * (P + 1);
         double acc = p[P];
 #pragma unroll
         for (int o = 1; o <= P; ++o) {

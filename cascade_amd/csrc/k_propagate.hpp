@@ -14,10 +14,16 @@
 //   coefficient recurrences, Jorba-Zou step size, terminal events, dfloat time.
 //
 // Layout. state [N][7] f64 (reference layout, sim.hpp:123). Pass 1 writes nsub[N],
-// status/event records, final_state [N][6], lbs/ubs [C][N][4] f32. Pass 2 writes
-// tcs [sum nsub][7][P+1] f64 and tcoords [sum nsub][2] f64 (hi, lo) at the CSR row
-// tc_off[i] + s: every particle-substep owns 1176 contiguous bytes (P = 20), which is
-// what the narrow phase wants (504 contiguous bytes for x, y, z).
+// status/event records, final_state [N][6], lbs/ubs [C][N][4] f32. Pass 2 runs AFTER the
+// Morton sort, one lane per particle in Morton order of chunk 0 (order[k]), and writes
+// exact-fit CSR rows: row_base[k] + s holds
+//   tcs_xyz [row][TC_XYZ_STRIDE]  x, y, z coefficients back to back (3 (P+1) doubles, padded
+//                                 to 64 doubles = 512 B = 4 cache lines for P = 20): all the
+//                                 narrow phase's fast path reads, 16-byte aligned;
+//   tcs_vr  [row][4 (P+1)]        vx, vy, vz, r (conjunction states and dense output only);
+//   tcoords [row][2]              substep end time (hi, lo) relative to the superstep start.
+// tc_row[i] = first row of particle i. Rows of spatial neighbours are neighbours in memory,
+// which is what keeps the narrow phase's gathers in L2.
 //
 // Roofline: pass 1 is FP64-VALU bound (~3.4 kFLOP per substep, no memory beyond 56 B
 // in / 84 B out per particle); pass 2 is HBM-write bound (1176 + 16 B per substep).
@@ -65,10 +71,23 @@ struct prop_params {
     double *final_state; // [N][6]
     float *lbs, *ubs;    // [C][N][4]
     // pass 2
-    const std::uint64_t *tc_off; // [N + 1]
-    double *tcs;
+    const std::uint32_t *order;     // [N] particle handled by lane k (null = identity)
+    const std::uint64_t *row_base;  // [N] first CSR row of lane k
+    std::uint64_t *tc_row;          // [N] out: first CSR row of particle i
+    double *tcs_xyz;
+    double *tcs_vr;
     double *tcoords;
 };
+
+// Row strides (doubles) of the two coefficient arrays.
+constexpr int tc_xyz_stride(int P)
+{
+    return (3 * (P + 1) + 1) & ~1;
+}
+constexpr int tc_vr_stride(int P)
+{
+    return 4 * (P + 1);
+}
 
 // Coefficient n of a*b, ascending j, fma.
 template <int N>
@@ -212,9 +231,15 @@ CSC_DEV_NOINLINE double event_first_root(const double *g_in, double h, int direc
 template <int P, bool EVENTS, bool STORE>
 __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
 {
-    const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= prm.n) {
+    const std::uint32_t lane_k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane_k >= prm.n) {
         return;
+    }
+    std::uint32_t i = lane_k;
+    if constexpr (STORE) {
+        if (prm.order != nullptr) {
+            i = prm.order[lane_k];
+        }
     }
 
     tc_regs<P> t;
@@ -270,7 +295,8 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
 
     std::size_t row = 0;
     if constexpr (STORE) {
-        row = prm.tc_off[i];
+        row = prm.row_base[lane_k];
+        prm.tc_row[i] = row;
     }
 
     while (true) {
@@ -374,14 +400,20 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
                 flags |= ST_FLAG_BAD_TCOORD;
             }
             if constexpr (STORE) {
-                double *dst = prm.tcs + (row + ns) * static_cast<std::size_t>(7 * (P + 1));
-                const double *arrs[7] = {t.x, t.y, t.z, t.vx, t.vy, t.vz, t.r};
+                constexpr int XS = tc_xyz_stride(P), VS = tc_vr_stride(P);
+                double2 *dxyz = reinterpret_cast<double2 *>(prm.tcs_xyz + (row + ns) * static_cast<std::size_t>(XS));
+                const double *axyz[3] = {t.x, t.y, t.z};
 #pragma unroll
-                for (int c = 0; c < 7; ++c) {
+                for (int e = 0; e < XS; e += 2) {
+                    const double v0 = axyz[e / (P + 1)][e % (P + 1)];
+                    const double v1 = (e + 1 < 3 * (P + 1)) ? axyz[(e + 1) / (P + 1)][(e + 1) % (P + 1)] : 0.;
+                    dxyz[e / 2] = make_double2(v0, v1);
+                }
+                double2 *dvr = reinterpret_cast<double2 *>(prm.tcs_vr + (row + ns) * static_cast<std::size_t>(VS));
+                const double *avr[4] = {t.vx, t.vy, t.vz, t.r};
 #pragma unroll
-                    for (int o = 0; o <= P; ++o) {
-                        dst[c * (P + 1) + o] = arrs[c][o];
-                    }
+                for (int e = 0; e < VS; e += 2) {
+                    dvr[e / 2] = make_double2(avr[e / (P + 1)][e % (P + 1)], avr[(e + 1) / (P + 1)][(e + 1) % (P + 1)]);
                 }
                 prm.tcoords[(row + ns) * 2u] = tc.hi;
                 prm.tcoords[(row + ns) * 2u + 1u] = tc.lo;

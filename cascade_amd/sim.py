@@ -374,6 +374,11 @@ class sim:
             cfg.reentry_c0 = self._reentry_radius * self._reentry_radius
         return cfg
 
+    def _tc_strides(self):
+        xs, vs = C.c_uint32(), C.c_uint32()
+        self._ctx._chk(self._ctx.L.csc_tc_strides(self._order, C.byref(xs), C.byref(vs)))
+        return int(xs.value), int(vs.value)
+
     def upload_state(self):
         """Host -> device copy of the state (the host arrays are the source of truth at
         every step() entry, cascade.py/core.cpp:199-230)."""
@@ -431,7 +436,7 @@ class sim:
         d_scodes = self._buf("srt_codes", (nchunks0, n), u64)
         d_slbs = self._buf("srt_lbs", (nchunks0, n, 4), f32)
         d_subs = self._buf("srt_ubs", (nchunks0, n, 4), f32)
-        d_tc_off = self._buf("tc_off", (n + 1,), u64)
+        d_tc_row = self._buf("tc_row", (n,), u64)
 
         ms = {}
 
@@ -479,18 +484,21 @@ class sim:
                 )
             nchunks = new_nchunks
 
-        # Taylor coefficients for dense output (CSR).
-        tot = int(summ.total_substeps)
-        chk(L.csc_exclusive_scan(h, d_nsub, n, d_tc_off))
-        d_tcs = self._buf("tcs", (max(tot, 1), 7, self._order + 1), f64)
-        d_tco = self._buf("tcoords", (max(tot, 1), 2), f64)
-        chk(L.csc_propagate_store(h, C.byref(cfg), n, d_state, d_tc_off, d_tcs, d_tco))
-        lap("store_tcs")
-
         chk(L.csc_global_aabb(h, n, nchunks, d_lbs, d_ubs, d_glb, d_gub))
         chk(L.csc_morton_encode(h, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes))
         chk(L.csc_sort_gather(h, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs))
         lap("morton_sort")
+
+        # Taylor coefficients for dense output: CSR rows in the Morton order of chunk 0, so
+        # that the rows the narrow phase gathers for neighbouring pairs are neighbours in HBM.
+        tot = int(summ.total_substeps)
+        self.last_total_substeps = tot
+        xs, vs = self._tc_strides()
+        d_txyz = self._buf("tcs_xyz", (max(tot, 1), xs), f64)
+        d_tvr = self._buf("tcs_vr", (max(tot, 1), vs), f64)
+        d_tco = self._buf("tcoords", (max(tot, 1), 2), f64)
+        chk(L.csc_propagate_store(h, C.byref(cfg), n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco))
+        lap("store_tcs")
         chk(L.csc_bvh_build(h, n, nchunks, d_scodes, d_slbs, d_subs))
         lap("bvh")
         npairs = C.c_uint64()
@@ -504,7 +512,7 @@ class sim:
         ncoll, nconj, warn = C.c_uint64(), C.c_uint64(), C.c_uint32()
         chk(
             L.csc_narrow_phase(
-                h, n, nchunks, self._ct, delta_t, self._time.hi, self._time.lo, self._conj_thresh, self._order, d_state, d_active, d_tc_off, d_tcs, d_tco, C.byref(ncoll), C.byref(nconj), C.byref(warn)
+                h, n, nchunks, self._ct, delta_t, self._time.hi, self._time.lo, self._conj_thresh, self._order, d_state, d_active, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, C.byref(ncoll), C.byref(nconj), C.byref(warn)
             )
         )
         coll = np.empty(int(ncoll.value), dtype=_capi.COLL_DTYPE)
@@ -537,7 +545,7 @@ class sim:
             if with_conj:
                 self._append_conj(conj)
         else:
-            chk(L.csc_dense_propagate(h, n, self._order, interrupt_time, d_tc_off, d_tcs, d_tco, d_final))
+            chk(L.csc_dense_propagate(h, n, self._order, interrupt_time, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_final))
             rc = L.csc_check_flags(h)
             if rc == -7:
                 raise ValueError("The computation of dense_propagate() could not be performed because no timesteps have been taken for a particle")
@@ -573,13 +581,23 @@ class sim:
         self._set_conj(np.concatenate([self._conj, new]))
         return first
 
+    def bp_nodes_visited(self):
+        """Measurement aid: BVH nodes tested by the broad phase of the last step()."""
+        n = self.nparts
+        nchunks = self._last[0]
+        d = self._dev
+        v = C.c_uint64()
+        self._ctx._chk(self._ctx.L.csc_broad_phase_stats(self._ctx.h, n, nchunks, d["srt_lbs"].ptr, d["srt_ubs"].ptr, d["vidx"].ptr, d["active"].ptr, C.byref(v)))
+        return int(v.value)
+
     # ---- dense output / propagate_until (:1386-1603) ----------------------------------
     def _dense_to(self, t_rel):
         n = self.nparts
         L, h, chk = self._ctx.L, self._ctx.h, self._ctx._chk
         d_state = self._buf("state", (n, 7), np.float64)
         d_final = self._buf("final_state", (n, 6), np.float64)
-        chk(L.csc_dense_propagate(h, n, self._order, t_rel, self._dev["tc_off"].ptr, self._dev["tcs"].ptr, self._dev["tcoords"].ptr, d_final))
+        d = self._dev
+        chk(L.csc_dense_propagate(h, n, self._order, t_rel, d["tc_row"].ptr, d["nsub"].ptr, d["tcs_xyz"].ptr, d["tcs_vr"].ptr, d["tcoords"].ptr, d_final))
         rc = L.csc_check_flags(h)
         if rc == -7:
             raise ValueError("The computation of dense_propagate() could not be performed because no timesteps have been taken for a particle")

@@ -156,10 +156,16 @@ int csc_propagate_summary(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, cons
 int csc_exclusive_scan(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out);
 
 /* Second pass: stores the Taylor coefficients (sim_data::step_data, sim_data.hpp:144-159)
- * in CSR form: row d_tc_off[i] + s holds tcs [7][p + 1] f64 and tcoords {hi, lo}. d_tc_off
- * [n + 1] is the exclusive scan of d_nsub. Asynchronous. */
+ * as exact-fit CSR rows. Lane k handles particle d_order[k] (NULL = identity; the simulation
+ * passes the Morton permutation of chunk 0 so that rows of spatial neighbours are neighbours
+ * in memory) and owns rows [base, base + d_nsub[i]); d_tc_row[i] (out, [n] u64) = base.
+ * Row r holds d_tcs_xyz [r][xyz_stride] (x, y, z coefficients back to back, zero padded),
+ * d_tcs_vr [r][vr_stride] (vx, vy, vz, r) and d_tcoords [r][2] {hi, lo}; the strides (in
+ * doubles) come from csc_tc_strides (64 and 84 for order 20). Asynchronous. */
+int csc_tc_strides(uint32_t order, uint32_t *xyz_stride, uint32_t *vr_stride);
 int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state,
-                        const uint64_t *d_tc_off, double *d_tcs, double *d_tcoords);
+                        const uint32_t *d_order, const uint32_t *d_nsub, uint64_t *d_tc_row, double *d_tcs_xyz,
+                        double *d_tcs_vr, double *d_tcoords);
 
 /* Per-chunk global AABB (src/sim_propagate.cpp:883-920, src/detail/atomic_utils.cpp:20-55;
  * exact like verify_global_aabbs :1348-1380). d_glb / d_gub [nchunks][4] f32 (upper bound NOT
@@ -196,11 +202,18 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
 /* ---- K6: broad phase -------------------------------------------------------------------
  * broad_phase_parallel (src/sim_broad_phase.cpp:44-218) on the trees of the last
  * csc_bvh_build. d_active [n] u8: bit 0 coll_active, bit 1 conj_active
- * (src/sim_propagate.cpp:639-647). The pair list lives in the context: pairs of chunk c are
- * rows [off[c], off[c + 1]) of a [total][2] u32 array, grouped by query particle in Morton
- * order. Synchronises (the total is needed to size the list); *n_pairs = total over chunks. */
+ * (src/sim_propagate.cpp:639-647). The pair list lives in the context: one {i, j, chunk, 0}
+ * u32x4 record per pair (i < j), all chunks in one list, in no particular order (the
+ * reference's per-chunk vectors are unordered too, tbb::concurrent_vector). Synchronises
+ * (the total is read back); *n_pairs = total over chunks. */
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs);
+/* Diagnostic (measurement only): re-runs the traversal of the last csc_broad_phase without
+ * writing pairs and returns the number of node AABB tests, i.e. the reference's "nodes
+ * visited" (every node popped from the stack of src/sim_broad_phase.cpp:121-196), summed over
+ * queries and chunks. Synchronises. */
+int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                          const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *nodes_visited);
 /* Copies the pairs of one chunk to the host (for parity checks). *count = number of pairs;
  * at most cap pairs are written. Synchronises. */
 int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t cap, uint64_t *count);
@@ -211,15 +224,17 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
  * (:560). Results live in the context; synchronises; counts returned. */
 int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                      double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
-                     const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs, const double *d_tcoords,
-                     uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags);
+                     const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
+                     const double *d_tcs_vr, const double *d_tcoords, uint64_t *n_coll, uint64_t *n_conj,
+                     uint32_t *warn_flags);
 /* Same, on a caller-provided pair list d_pairs [npairs][2] with per-chunk row offsets
  * pair_off [nchunks + 1] (host array). For parity checks on injected pairs. */
 int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                            double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
-                           const uint8_t *d_active, const uint64_t *d_tc_off, const double *d_tcs,
-                           const double *d_tcoords, const uint32_t *d_pairs, const uint64_t *pair_off,
-                           uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags);
+                           const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub,
+                           const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords,
+                           const uint32_t *d_pairs, const uint64_t *pair_off, uint64_t *n_coll, uint64_t *n_conj,
+                           uint32_t *warn_flags);
 int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,
                          uint64_t conj_cap); /* host copies, sorted by (time, i, j) */
 
@@ -227,8 +242,9 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
  * dense_propagate (src/sim_propagate.cpp:1386-1503): state of every particle at time t
  * (relative to the superstep start) into d_out [n][6]. Asynchronous; a particle without
  * substeps raises CSC_ERR_NO_SUBSTEPS through csc_check_flags. */
-int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, const uint64_t *d_tc_off,
-                        const double *d_tcs, const double *d_tcoords, double *d_out);
+int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, const uint64_t *d_tc_row,
+                        const uint32_t *d_nsub, const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords,
+                        double *d_out);
 
 /* state[:, 0:6] <- final_state (copy_from_final_state, src/sim_propagate.cpp:1610-1630). */
 int csc_copy_final_state(csc_ctx *ctx, uint32_t n, const double *d_final_state, double *d_state);

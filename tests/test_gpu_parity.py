@@ -111,7 +111,25 @@ def test_aabb_to_pairs_bit_exact(orc, ctx, n, n_par_ct, same_code):
     assert tot == npairs.value
 
 
-def _gpu_propagate(ctx, st, cfg_kw):
+def _split_rows(tcs, nsub, order):
+    """Oracle coefficients [tot][7][21] (particle order) -> the library's CSR layout with the
+    rows of particle order[k] stored k-th: (tc_row [n], xyz [tot][64], vr [tot][84], row_perm)
+    where row_perm[new_row] = old_row."""
+    n = len(nsub)
+    off = np.concatenate([[0], np.cumsum(nsub)]).astype(np.int64)
+    ns_ord = nsub[order].astype(np.int64)
+    base = np.concatenate([[0], np.cumsum(ns_ord)])[:-1]
+    tc_row = np.zeros(n, np.uint64)
+    tc_row[order] = base.astype(np.uint64)
+    row_perm = np.concatenate([np.arange(off[i], off[i + 1]) for i in order]) if n else np.zeros(0, np.int64)
+    t = tcs[row_perm]
+    xyz = np.zeros((len(t), 64))
+    xyz[:, :63] = t[:, :3, :].reshape(len(t), 63)
+    vr = np.ascontiguousarray(t[:, 3:, :].reshape(len(t), 84))
+    return tc_row, xyz, vr, row_perm
+
+
+def _gpu_propagate(ctx, st, cfg_kw, order=None):
     from cascade_amd import _capi
 
     L, h, chk = ctx.L, ctx.h, ctx._chk
@@ -138,15 +156,26 @@ def _gpu_propagate(ctx, st, cfg_kw):
     chk(L.csc_propagate(h, C.byref(cfg), n, d_state.ptr, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, d["final"].ptr, d["lbs"].ptr, d["ubs"].ptr))
     summ = _capi.PropSummary()
     chk(L.csc_propagate_summary(h, n, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, C.byref(summ)))
-    d_off = ctx.empty(n + 1, np.uint64)
-    chk(L.csc_exclusive_scan(h, d["nsub"].ptr, n, d_off.ptr))
     tot = int(summ.total_substeps)
-    d_tcs = ctx.empty((max(tot, 1), 7, 21), np.float64)
+    xs, vs = C.c_uint32(), C.c_uint32()
+    chk(L.csc_tc_strides(20, C.byref(xs), C.byref(vs)))
+    assert (xs.value, vs.value) == (64, 84)
+    d_row = ctx.empty(n, np.uint64)
+    d_xyz = ctx.empty((max(tot, 1), 64), np.float64)
+    d_vr = ctx.empty((max(tot, 1), 84), np.float64)
     d_tco = ctx.empty((max(tot, 1), 2), np.float64)
-    chk(L.csc_propagate_store(h, C.byref(cfg), n, d_state.ptr, d_off.ptr, d_tcs.ptr, d_tco.ptr))
+    d_order = ctx.array(np.asarray(order, dtype=np.uint32)) if order is not None else None
+    chk(L.csc_propagate_store(h, C.byref(cfg), n, d_state.ptr, d_order.ptr if d_order else None, d["nsub"].ptr, d_row.ptr, d_xyz.ptr, d_vr.ptr, d_tco.ptr))
     out = {k: v.download() for k, v in d.items()}
-    out.update(summ=summ, off=d_off.download(), tcs=d_tcs.download()[:tot], tco=d_tco.download()[:tot])
-    out["dev"] = dict(state=d_state, off=d_off, tcs=d_tcs, tco=d_tco)
+    # Back to the oracle's layout: [tot][7][21] with the rows in particle order.
+    row, xyz, vr, tco = d_row.download(), d_xyz.download()[:tot], d_vr.download()[:tot], d_tco.download()[:tot]
+    nsub = out["nsub"]
+    rows = np.concatenate([np.arange(row[i], row[i] + nsub[i]) for i in range(n)]).astype(np.int64) if tot else np.zeros(0, np.int64)
+    assert len(rows) == tot and np.array_equal(np.sort(rows), np.arange(tot)), "rows are a partition"
+    assert np.all(xyz[:, 63] == 0.0)
+    tcs = np.concatenate([xyz[rows, :63].reshape(tot, 3, 21), vr[rows].reshape(tot, 4, 21)], axis=1)
+    out.update(summ=summ, row=row, tcs=tcs, tco=tco[rows])
+    out["dev"] = dict(state=d_state, row=d_row, nsub=d["nsub"], xyz=d_xyz, vr=d_vr, tco=d_tco)
     return out
 
 
@@ -179,7 +208,8 @@ def test_propagate_parity(orc, ctx, n, ct, n_par_ct, conj):
     s.time = 3.25
     assert s.step() in ("success", "collision")
     nsub, tcs, tco = s.substeps()
-    g = _gpu_propagate(ctx, st, _cfg_kw(orc, ct, n_par_ct, conj, t0=(3.25, 0.0)))
+    order = np.random.default_rng(n).permutation(n) if n_par_ct > 1 else None
+    g = _gpu_propagate(ctx, st, _cfg_kw(orc, ct, n_par_ct, conj, t0=(3.25, 0.0)), order=order)
     assert np.array_equal(g["nsub"], nsub)
     assert np.all((g["status"] & 0xFF) == 0) and g["summ"].flags == 0
     assert _rel_close(g["tco"][:, 0], tco[:, 0])
@@ -231,18 +261,20 @@ def test_narrow_phase_injected(orc, ctx, n, n_par_ct, conj):
     s.time = 1.5
     oc = s.step()
     nsub, tcs, tco = s.substeps()
-    off = np.concatenate([[0], np.cumsum(nsub)]).astype(np.uint64)
+    order = np.random.default_rng(5).permutation(n)
+    tc_row, xyz, vr, row_perm = _split_rows(tcs, nsub, order)
     pairs = [s.bp_pairs(c) for c in range(s.nchunks)]
     poff = np.concatenate([[0], np.cumsum([len(p) for p in pairs])]).astype(np.uint64)
     allp = np.concatenate(pairs) if poff[-1] else np.zeros((0, 2), np.uint32)
     ca, cj = s.active_flags()
     L, h, chk = ctx.L, ctx.h, ctx._chk
     d_state, d_act = ctx.array(st), ctx.array((ca | (cj << 1)).astype(np.uint8))
-    d_off, d_tcs, d_tco, d_pairs = ctx.array(off), ctx.array(tcs), ctx.array(tco), ctx.array(allp)
+    d_row, d_ns, d_xyz, d_vr = ctx.array(tc_row), ctx.array(nsub.astype(np.uint32)), ctx.array(xyz), ctx.array(vr)
+    d_tco, d_pairs = ctx.array(tco[row_perm]), ctx.array(allp)
     ncoll, nconj, warn = C.c_uint64(), C.c_uint64(), C.c_uint32()
     chk(
         L.csc_narrow_phase_pairs(
-            h, n, s.nchunks, 0.23, s.delta_t, 1.5, 0.0, conj, 20, d_state.ptr, d_act.ptr, d_off.ptr, d_tcs.ptr, d_tco.ptr, d_pairs.ptr, poff.ctypes.data_as(C.c_void_p), C.byref(ncoll), C.byref(nconj), C.byref(warn)
+            h, n, s.nchunks, 0.23, s.delta_t, 1.5, 0.0, conj, 20, d_state.ptr, d_act.ptr, d_row.ptr, d_ns.ptr, d_xyz.ptr, d_vr.ptr, d_tco.ptr, d_pairs.ptr, poff.ctypes.data_as(C.c_void_p), C.byref(ncoll), C.byref(nconj), C.byref(warn)
         )
     )
     from cascade_amd import _capi
@@ -270,15 +302,15 @@ def test_dense_output(orc, ctx):
     orc.lib().orc_rhofac.restype = C.c_double
     orc.lib().orc_rhofac.argtypes = [C.c_uint32]
     st = _pop(500, seed=3)
-    g = _gpu_propagate(ctx, st, _cfg_kw(orc, 0.23, 4))
+    g = _gpu_propagate(ctx, st, _cfg_kw(orc, 0.23, 4), order=np.random.default_rng(1).permutation(500))
     L, h, chk = ctx.L, ctx.h, ctx._chk
     d_out = ctx.empty((500, 6), np.float64)
     # state at t = full superstep must reproduce the final state to rounding
-    chk(L.csc_dense_propagate(h, 500, 20, 0.92, g["dev"]["off"].ptr, g["dev"]["tcs"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
+    chk(L.csc_dense_propagate(h, 500, 20, 0.92, g["dev"]["row"].ptr, g["dev"]["nsub"].ptr, g["dev"]["xyz"].ptr, g["dev"]["vr"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
     chk(L.csc_check_flags(h))
     assert np.allclose(d_out.download(), g["final"], rtol=0, atol=1e-14)
     # mid-superstep: compare with an oracle propagate_until (which uses dense output)
     s = orc.Sim(st, 0.23, n_par_ct=4)
     assert s.propagate_until(0.5) == "time_limit"
-    chk(L.csc_dense_propagate(h, 500, 20, 0.5, g["dev"]["off"].ptr, g["dev"]["tcs"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
+    chk(L.csc_dense_propagate(h, 500, 20, 0.5, g["dev"]["row"].ptr, g["dev"]["nsub"].ptr, g["dev"]["xyz"].ptr, g["dev"]["vr"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
     assert _rel_close(d_out.download(), s.state[:, :6])
