@@ -384,9 +384,10 @@ __global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_
     t.lb1 = b.nlb[no + l + 1];
     t.ub1 = b.nub[no + l + 1];
     const std::uint32_t b0 = b.nb[no + l], b1 = b.nb[no + l + 1];
-    t.c0 = make_int4(b.nleft[no + l], static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(vx[b0]));
-    t.c1 = make_int4(b.nleft[no + l + 1], static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]),
-                     static_cast<int>(vx[b1]));
+    // Descriptor .x = the child's OWN canonical index when it is internal, -1 when it is a leaf.
+    const int own0 = b.nleft[no + l] < 0 ? -1 : l, own1 = b.nleft[no + l + 1] < 0 ? -1 : l + 1;
+    t.c0 = make_int4(own0, static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(vx[b0]));
+    t.c1 = make_int4(own1, static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]), static_cast<int>(vx[b1]));
     tn[no + p] = t;
 }
 
