@@ -43,7 +43,7 @@ struct csc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<std::string, dbuf> bufs;
-    int *d_flags = nullptr; // [0] morton non-finite box, [1] dense: no substeps
+    int *d_flags = nullptr; // [0] morton non-finite box, [1] dense: no substeps, [2] broad-phase stack overflow
     // BVH state of the last csc_bvh_build
     csc::bvh_bufs bvh{};
     uint32_t bvh_n = 0, bvh_chunks = 0;
@@ -511,10 +511,10 @@ int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap)
 
 int csc_check_flags(csc_ctx *ctx)
 {
-    int h[2] = {0, 0};
+    int h[3] = {0, 0, 0};
     CSC_HIP(hipMemcpyAsync(h, ctx->d_flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     CSC_HIP(hipStreamSynchronize(ctx->stream));
-    if (h[0] || h[1]) {
+    if (h[0] || h[1] || h[2]) {
         CSC_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(h), ctx->stream));
     }
     if (h[0]) {
@@ -524,6 +524,10 @@ int csc_check_flags(csc_ctx *ctx)
     if (h[1]) {
         ctx->err = "dense_propagate() could not be performed because no timesteps have been taken for a particle";
         return CSC_ERR_NO_SUBSTEPS;
+    }
+    if (h[2]) {
+        ctx->err = "broad phase traversal stack overflow (BVH deeper than 64 levels?)";
+        return CSC_ERR_OVERFLOW;
     }
     return CSC_OK;
 }
@@ -858,13 +862,12 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     }
     const size_t cnn = static_cast<size_t>(ctx->bvh_chunks) * ctx->bvh.nn_max;
     CSC_BUF(d_tn, csc::tnode, "bvh_tnodes", cnn);
-    if (!ctx->bvh_packed) {
-        // Wide traversal nodes (needs the Morton permutation for the leaf descriptors).
-        KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
-                                             ctx->stream, ctx->bvh, d_vidx, d_tn));
-        CSC_LAUNCH_CHECK();
-        ctx->bvh_packed = true;
-    }
+    // Wide traversal nodes (need the Morton permutation and the activity flags for the leaf
+    // descriptors, so they are rebuilt on every call).
+    KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
+                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn));
+    CSC_LAUNCH_CHECK();
+    ctx->bvh_packed = true;
     csc::bp_params q{};
     q.n = n;
     q.nn_max = ctx->bvh.nn_max;
@@ -877,7 +880,8 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     q.nleft = ctx->bvh.nleft;
     q.active = d_active;
     q.counter = ctx->d_bp_counter;
-    const dim3 grid(cdiv(n, csc::BP_BLOCK), nchunks), blk(csc::BP_BLOCK);
+    q.err_flag = ctx->d_flags + 2;
+    const dim3 grid(cdiv(n, 64), nchunks), blk(64);
     // The pair list is appended through a device counter; its capacity follows the last
     // superstep's count (populations change slowly), and an overflow re-runs the traversal.
     uint64_t cap = std::max<uint64_t>({ctx->bp_cap, static_cast<uint64_t>(n) * nchunks * 8u, 1u << 16});
@@ -886,8 +890,12 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
         CSC_BUF(d_pairs, uint4, "bp_pairs", cap);
         q.pairs = d_pairs;
         q.cap = cap;
+#ifdef BPG_DEBUG_STATS
+        CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, 8 * sizeof(unsigned long long), ctx->stream));
+#else
         CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, sizeof(unsigned long long), ctx->stream));
-        KT("k_broad_phase", hipLaunchKernelGGL((csc::k_broad_phase<false>), grid, blk, 0, ctx->stream, q));
+#endif
+        KT("k_broad_phase", hipLaunchKernelGGL(csc::k_broad_phase, grid, blk, 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(&total, ctx->d_bp_counter, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
@@ -926,8 +934,9 @@ int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const floa
     q.nleft = ctx->bvh.nleft;
     q.active = d_active;
     q.counter = ctx->d_bp_counter;
+    q.err_flag = ctx->d_flags + 2;
     CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL((csc::k_broad_phase<true>), dim3(cdiv(n, csc::BP_BLOCK), nchunks), dim3(csc::BP_BLOCK), 0, ctx->stream, q);
+    hipLaunchKernelGGL(csc::k_broad_phase_stats, dim3(cdiv(n, csc::BP_BLOCK), nchunks), dim3(csc::BP_BLOCK), 0, ctx->stream, q);
     CSC_LAUNCH_CHECK();
     unsigned long long v = 0;
     CSC_HIP(hipMemcpyAsync(&v, ctx->d_bp_counter + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
@@ -935,6 +944,14 @@ int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const floa
     *nodes_visited = v;
     return CSC_OK;
 }
+
+#ifdef BPG_DEBUG_STATS
+int csc_debug_counters(csc_ctx *ctx, unsigned long long *out)
+{
+    CSC_HIP(hipMemcpy(out, ctx->d_bp_counter, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CSC_OK;
+}
+#endif
 
 int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t cap, uint64_t *count)
 {

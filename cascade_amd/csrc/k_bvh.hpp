@@ -340,25 +340,34 @@ __global__ __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t ch
 // ---------------------------------------------------------------------------
 // K6: broad phase. Replaces src/sim_broad_phase.cpp:92-202.
 //
-// Traversal layout ("wide" nodes): every internal node carries the AABBs and descriptors of
-// BOTH children in one 96-byte record, so one fetch decides two subtrees and a child that
-// does not overlap is never fetched at all. A child descriptor is {left, begin, end, orig}:
-// left = canonical index of the child's own record (-1 for a leaf), [begin, end) its
-// particle range, orig = original index of the first particle (saves the vidx lookup for
-// single-particle leaves). The tests performed are exactly the reference's (closed-interval
-// overlap of the query AABB with the node AABB on 4 dimensions, leaf test against the LEAF
-// NODE box, pairs (orig_pidx < orig_i) with at least one activity flag), only their order
-// differs, so the pair SET is identical.
+// What the reference computes. For every particle p it walks the tree from the root and
+// descends into every node whose AABB overlaps p's AABB (closed intervals, 4 dimensions,
+// :149-151); at a leaf it emits (orig_p, orig_i) for every member i with orig_p < orig_i and
+// at least one activity flag (:175-185). A parent box is the exact float union of its
+// children's boxes, so "p overlaps the leaf's box" implies "p overlaps every ancestor": the
+// pair set is {(p, i) : box(p) overlaps box(leaf(i)), orig_p < orig_i, active}. Any traversal
+// that reaches a superset of those leaves and then applies that final test yields the
+// IDENTICAL set; only the order of the list differs (the reference's own order is
+// unspecified: tbb::concurrent_vector).
 //
-// One lane per Morton-ordered particle, DFS stack in LDS, pairs appended to one global list
-// through a device counter (the compiler folds the per-lane atomicAdd(.., 1) into one atomic
-// per wave instruction). A pair record is {i, j, chunk, 0} (16 bytes, one store). The list
-// order is not deterministic; every consumer is order-independent.
-// Traffic: 96 B per visited internal node (L2-resident near the root) + 16 B per pair.
+// Wavefront-cooperative traversal. One wave owns 64 Morton-consecutive query particles and
+// walks the tree ONCE for all of them with the union of their boxes (Morton neighbours have
+// nearly coincident boxes, so the union visits about the nodes a single query visits, at
+// 1/64 of the fetches). The walk itself is breadth-parallel: every round up to 64 pending
+// nodes are popped from the wave's LDS stack, one per lane, each lane tests both children
+// of its node against the group box (one 96-byte "wide" record per node: both child boxes
+// and descriptors), overlapping internal children are pushed back (ballot-compacted),
+// overlapping leaves go to an LDS leaf queue. Then the queue is drained: per leaf, all 64
+// lanes test their OWN box against the leaf box and the hits are ballot-compacted into an
+// LDS pair buffer that is flushed with one global atomic per ~200 pairs and fully coalesced
+// 16-byte stores. There is no per-lane divergence anywhere and no dependent-load chain
+// longer than the tree depth.
+//
+// A child descriptor is {tag, begin, end, orig}: tag = the child's own canonical index when it
+// is internal; for a leaf tag = -1 - act where act is the activity byte of its (first)
+// particle; [begin, end) the particle range; orig the original index of the first particle.
+// Pair record: {i, j, chunk, 0} u32x4.
 // ---------------------------------------------------------------------------
-constexpr int BP_BLOCK = 64;
-constexpr int BP_STACK = 72; // depth <= 64 -> at most 65 pending entries
-
 struct tnode {
     float4 lb0, ub0, lb1, ub1;
     int4 c0, c1;
@@ -366,7 +375,8 @@ struct tnode {
 static_assert(sizeof(tnode) == 96, "wide node layout");
 
 // One thread per canonical node; internal nodes fill their record.
-__global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, tnode *tn)
+__global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, const std::uint8_t *active,
+                                                  tnode *tn)
 {
     const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= b.n_nodes[c]) {
@@ -384,10 +394,11 @@ __global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_
     t.lb1 = b.nlb[no + l + 1];
     t.ub1 = b.nub[no + l + 1];
     const std::uint32_t b0 = b.nb[no + l], b1 = b.nb[no + l + 1];
-    // Descriptor .x = the child's OWN canonical index when it is internal, -1 when it is a leaf.
-    const int own0 = b.nleft[no + l] < 0 ? -1 : l, own1 = b.nleft[no + l + 1] < 0 ? -1 : l + 1;
-    t.c0 = make_int4(own0, static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(vx[b0]));
-    t.c1 = make_int4(own1, static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]), static_cast<int>(vx[b1]));
+    const std::uint32_t o0 = vx[b0], o1 = vx[b1];
+    const int tag0 = b.nleft[no + l] < 0 ? -1 - static_cast<int>(active[o0]) : l;
+    const int tag1 = b.nleft[no + l + 1] < 0 ? -1 - static_cast<int>(active[o1]) : l + 1;
+    t.c0 = make_int4(tag0, static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(o0));
+    t.c1 = make_int4(tag1, static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]), static_cast<int>(o1));
     tn[no + p] = t;
 }
 
@@ -402,7 +413,8 @@ struct bp_params {
     const std::uint8_t *active;  // [n] bit0 coll_active, bit1 conj_active
     uint4 *pairs;                // [cap] {i, j, chunk, 0}
     std::uint64_t cap;
-    unsigned long long *counter; // number of pairs found (may exceed cap: overflow)
+    unsigned long long *counter; // [0] pairs found (may exceed cap: overflow), [1] statistics
+    int *err_flag;               // traversal stack overflow (cannot happen for depth <= 64)
 };
 
 CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, const float4 &nu)
@@ -411,28 +423,160 @@ CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, 
            && (pub.w >= nl.w && plb.w <= nu.w);
 }
 
-CSC_DEV void bp_emit_leaf(const bp_params &q, std::uint32_t c, std::size_t po, std::uint32_t orig_pidx, bool act_p,
-                          const int4 &cd)
+constexpr int BPG_STACK = 768; // pending internal nodes of one wave
+constexpr int BPG_PAIRQ = 256; // staged pairs of one wave
+
+__global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
 {
-    const std::uint32_t b = static_cast<std::uint32_t>(cd.y), e = static_cast<std::uint32_t>(cd.z);
-    for (std::uint32_t i = b; i != e; ++i) {
-        const std::uint32_t orig_i = (i == b) ? static_cast<std::uint32_t>(cd.w) : q.vidx[po + i];
-        if (orig_pidx >= orig_i) {
-            continue;
+    __shared__ std::int32_t stack[BPG_STACK];
+    __shared__ tnode stage[64];
+    __shared__ uint2 pairq[BPG_PAIRQ];
+    const std::uint32_t c = blockIdx.y;
+    const int lane = threadIdx.x;
+    const std::uint32_t pidx = blockIdx.x * 64u + lane;
+    const bool valid = pidx < q.n;
+    const std::size_t po = static_cast<std::size_t>(c) * q.n;
+    const std::size_t no = static_cast<std::size_t>(c) * q.nn_max;
+    const float finf = __builtin_huge_valf();
+    // Lanes past the end carry an empty box: they never overlap anything.
+    float4 plb = make_float4(finf, finf, finf, finf), pub = make_float4(-finf, -finf, -finf, -finf);
+    std::uint32_t orig_p = 0xffffffffu;
+    bool act_p = false;
+    if (valid) {
+        plb = q.slb[po + pidx];
+        pub = q.sub[po + pidx];
+        orig_p = q.vidx[po + pidx];
+        act_p = q.active[orig_p] != 0;
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int sp = 0, npq = 0;
+
+    auto flush = [&]() {
+        __syncthreads();
+        unsigned long long base = 0;
+        if (lane == 0) {
+            base = atomicAdd(q.counter, static_cast<unsigned long long>(npq));
         }
-        if (act_p || q.active[orig_i] != 0) {
-            const unsigned long long slot = atomicAdd(q.counter, 1ull);
+        base = __shfl(base, 0);
+        for (int k = lane; k < npq; k += 64) {
+            const unsigned long long slot = base + static_cast<unsigned long long>(k);
             if (slot < q.cap) {
-                q.pairs[slot] = make_uint4(orig_pidx, orig_i, c, 0u);
+                const uint2 pr = pairq[k];
+                q.pairs[slot] = make_uint4(pr.x, pr.y, c, 0u);
             }
         }
+        npq = 0;
+        __syncthreads();
+    };
+    auto emit = [&](bool e, std::uint32_t oi) {
+        const unsigned long long mask = __ballot(e);
+        if (mask != 0ull) {
+            if (e) {
+                pairq[npq + __popcll(mask & lt_mask)] = make_uint2(orig_p, oi);
+            }
+            npq += __popcll(mask);
+            if (npq > BPG_PAIRQ - 64) {
+                flush();
+            }
+        }
+    };
+    // A leaf whose box at least one lane overlaps (hit = this lane's test).
+    auto leaf = [&](bool hit, const int4 &d) {
+        if (d.z - d.y == 1) {
+            const std::uint32_t oi = static_cast<std::uint32_t>(d.w);
+            emit(hit && orig_p < oi && (act_p || d.x != -1), oi);
+        } else {
+            // Multi-particle leaf (equal Morton codes): the test is against the LEAF box for
+            // every member (src/sim_broad_phase.cpp:161-168).
+            for (std::uint32_t m = static_cast<std::uint32_t>(d.y); m != static_cast<std::uint32_t>(d.z); ++m) {
+                const std::uint32_t oi = q.vidx[po + m];
+                emit(hit && orig_p < oi && (act_p || q.active[oi] != 0), oi);
+            }
+        }
+    };
+
+    {
+        const bool hroot = bp_overlap(plb, pub, q.nlb[no], q.nub[no]);
+        if (__ballot(hroot) == 0ull) {
+            return;
+        }
+        if (q.nleft[no] < 0) {
+            // The whole tree is one leaf.
+            const std::uint32_t o0 = q.vidx[po];
+            leaf(hroot, make_int4(-1 - static_cast<int>(q.active[o0]), 0, static_cast<int>(q.n), static_cast<int>(o0)));
+        } else {
+            if (lane == 0) {
+                stack[0] = 0;
+            }
+            sp = 1;
+        }
+    }
+    __syncthreads();
+
+    while (sp > 0) {
+        // Pop up to 64 nodes and fetch their records in parallel, one per lane. Near the stack
+        // capacity fall back to one node per round (plain depth-first: the stack then grows by
+        // at most the remaining tree depth).
+        const int np = (sp > BPG_STACK - 192) ? 1 : (sp < 64 ? sp : 64);
+        if (lane < np) {
+            stage[lane] = q.tn[no + stack[sp - 1 - lane]];
+        }
+        sp -= np;
+#ifdef BPG_DEBUG_STATS
+        if (lane == 0) {
+            atomicAdd(q.counter + 2, (unsigned long long)np);
+            atomicAdd(q.counter + 4, 1ull);
+        }
+#endif
+        __syncthreads();
+        for (int k = 0; k < np; ++k) {
+            const tnode &t = stage[k];
+            const int4 c0 = t.c0, c1 = t.c1;
+            const bool h0 = bp_overlap(plb, pub, t.lb0, t.ub0), h1 = bp_overlap(plb, pub, t.lb1, t.ub1);
+            const bool any0 = __ballot(h0) != 0ull, any1 = __ballot(h1) != 0ull;
+            if (any0) {
+                if (c0.x >= 0) {
+                    if (lane == 0) {
+                        stack[sp] = c0.x;
+                    }
+                    ++sp;
+                } else {
+                    leaf(h0, c0);
+                }
+            }
+            if (any1) {
+                if (c1.x >= 0) {
+                    if (lane == 0) {
+                        stack[sp] = c1.x;
+                    }
+                    ++sp;
+                } else {
+                    leaf(h1, c1);
+                }
+            }
+        }
+        if (sp > BPG_STACK - 130) {
+            // Cannot happen for trees of depth <= 64 (see np above); never write out of bounds.
+            if (lane == 0) {
+                atomicOr(q.err_flag, 1);
+            }
+            return;
+        }
+        __syncthreads();
+    }
+    if (npq > 0) {
+        flush();
     }
 }
 
-// STATS = true: diagnostic variant, writes nothing and adds the number of node AABB tests
-// (the reference's "nodes visited": every node popped from its stack) to counter[1].
-template <bool STATS>
-__global__ __launch_bounds__(BP_BLOCK) void k_broad_phase(bp_params q)
+// Diagnostic: the reference's per-particle traversal (one lane per query, DFS stack in LDS),
+// writing nothing and adding the number of node AABB tests (the reference's "nodes visited":
+// every node popped from the stack of src/sim_broad_phase.cpp:121-196) to counter[1]. This is
+// the unit count behind the broad phase's algorithmic bytes.
+constexpr int BP_BLOCK = 64;
+constexpr int BP_STACK = 72; // depth <= 64 -> at most 65 pending entries
+
+__global__ __launch_bounds__(BP_BLOCK) void k_broad_phase_stats(bp_params q)
 {
     __shared__ std::int32_t stack[BP_STACK][BP_BLOCK];
     const std::uint32_t c = blockIdx.y;
@@ -443,19 +587,9 @@ __global__ __launch_bounds__(BP_BLOCK) void k_broad_phase(bp_params q)
     const int tid = threadIdx.x;
     const std::size_t po = static_cast<std::size_t>(c) * q.n;
     const std::size_t no = static_cast<std::size_t>(c) * q.nn_max;
-    const std::uint32_t orig_pidx = q.vidx[po + pidx];
-    const bool act_p = q.active[orig_pidx] != 0;
     const float4 plb = q.slb[po + pidx], pub = q.sub[po + pidx];
-    // Root.
-    if (!bp_overlap(plb, pub, q.nlb[no], q.nub[no])) {
-        return;
-    }
-    if constexpr (STATS) {
-        if (q.nleft[no] < 0) {
-            atomicAdd(q.counter + 1, 1ull);
-            return;
-        }
-        unsigned long long visits = 1;
+    unsigned long long visits = 1;
+    if (bp_overlap(plb, pub, q.nlb[no], q.nub[no]) && q.nleft[no] >= 0) {
         int sp = 0;
         stack[sp++][tid] = 0;
         do {
@@ -469,36 +603,8 @@ __global__ __launch_bounds__(BP_BLOCK) void k_broad_phase(bp_params q)
                 stack[sp++][tid] = t->c1.x;
             }
         } while (sp > 0);
-        atomicAdd(q.counter + 1, visits);
-        return;
     }
-    if (q.nleft[no] < 0) {
-        // The tree is a single (multi-particle) leaf.
-        bp_emit_leaf(q, c, po, orig_pidx, act_p, make_int4(-1, 0, static_cast<int>(q.n), static_cast<int>(q.vidx[po])));
-        return;
-    }
-    int sp = 0;
-    stack[sp++][tid] = 0;
-    do {
-        const std::int32_t node = stack[--sp][tid];
-        const tnode *t = q.tn + no + node;
-        const float4 lb0 = t->lb0, ub0 = t->ub0, lb1 = t->lb1, ub1 = t->ub1;
-        const int4 c0 = t->c0, c1 = t->c1;
-        if (bp_overlap(plb, pub, lb0, ub0)) {
-            if (c0.x < 0) {
-                bp_emit_leaf(q, c, po, orig_pidx, act_p, c0);
-            } else {
-                stack[sp++][tid] = c0.x;
-            }
-        }
-        if (bp_overlap(plb, pub, lb1, ub1)) {
-            if (c1.x < 0) {
-                bp_emit_leaf(q, c, po, orig_pidx, act_p, c1);
-            } else {
-                stack[sp++][tid] = c1.x;
-            }
-        }
-    } while (sp > 0);
+    atomicAdd(q.counter + 1, visits);
 }
 
 } // namespace csc
