@@ -895,7 +895,7 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
 #else
         CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, sizeof(unsigned long long), ctx->stream));
 #endif
-        KT("k_broad_phase", hipLaunchKernelGGL(csc::k_broad_phase, grid, blk, 0, ctx->stream, q));
+        KT("k_broad_phase", hipLaunchKernelGGL(csc::k_broad_phase, grid, blk, 0, ctx->stream, static_cast<const csc::tnode *>(d_tn), q));
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(&total, ctx->d_bp_counter, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));

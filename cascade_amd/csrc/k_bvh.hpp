@@ -426,10 +426,13 @@ CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, 
 constexpr int BPG_STACK = 768; // pending internal nodes of one wave
 constexpr int BPG_PAIRQ = 256; // staged pairs of one wave
 
-__global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
+// tn is passed on its own (not inside bp_params) so that it can carry __restrict__: with the
+// node index made wave-uniform (v_readlane) the compiler then fetches the 96-byte record with
+// scalar loads (s_load_dwordx8) into SGPRs, and the per-lane box tests take their node
+// operands straight from SGPRs: no LDS traffic and no VGPRs for the broadcast.
+__global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn, bp_params q)
 {
     __shared__ std::int32_t stack[BPG_STACK];
-    __shared__ tnode stage[64];
     __shared__ uint2 pairq[BPG_PAIRQ];
     const std::uint32_t c = blockIdx.y;
     const int lane = threadIdx.x;
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
     const bool valid = pidx < q.n;
     const std::size_t po = static_cast<std::size_t>(c) * q.n;
     const std::size_t no = static_cast<std::size_t>(c) * q.nn_max;
+    tn += no;
     const float finf = __builtin_huge_valf();
     // Lanes past the end carry an empty box: they never overlap anything.
     float4 plb = make_float4(finf, finf, finf, finf), pub = make_float4(-finf, -finf, -finf, -finf);
@@ -481,14 +485,14 @@ __global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
         }
     };
     // A leaf whose box at least one lane overlaps (hit = this lane's test).
-    auto leaf = [&](bool hit, const int4 &d) {
-        if (d.z - d.y == 1) {
-            const std::uint32_t oi = static_cast<std::uint32_t>(d.w);
-            emit(hit && orig_p < oi && (act_p || d.x != -1), oi);
+    auto leaf = [&](bool hit, int tag, int begin, int end, int orig) {
+        if (end - begin == 1) {
+            const std::uint32_t oi = static_cast<std::uint32_t>(orig);
+            emit(hit && orig_p < oi && (act_p || tag != -1), oi);
         } else {
             // Multi-particle leaf (equal Morton codes): the test is against the LEAF box for
             // every member (src/sim_broad_phase.cpp:161-168).
-            for (std::uint32_t m = static_cast<std::uint32_t>(d.y); m != static_cast<std::uint32_t>(d.z); ++m) {
+            for (std::uint32_t m = static_cast<std::uint32_t>(begin); m != static_cast<std::uint32_t>(end); ++m) {
                 const std::uint32_t oi = q.vidx[po + m];
                 emit(hit && orig_p < oi && (act_p || q.active[oi] != 0), oi);
             }
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
         if (q.nleft[no] < 0) {
             // The whole tree is one leaf.
             const std::uint32_t o0 = q.vidx[po];
-            leaf(hroot, make_int4(-1 - static_cast<int>(q.active[o0]), 0, static_cast<int>(q.n), static_cast<int>(o0)));
+            leaf(hroot, -1 - static_cast<int>(q.active[o0]), 0, static_cast<int>(q.n), static_cast<int>(o0));
         } else {
             if (lane == 0) {
                 stack[0] = 0;
@@ -514,25 +518,19 @@ __global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
     __syncthreads();
 
     while (sp > 0) {
-        // Pop up to 64 nodes and fetch their records in parallel, one per lane. Near the stack
-        // capacity fall back to one node per round (plain depth-first: the stack then grows by
-        // at most the remaining tree depth).
+        // Pop up to 64 pending nodes, lane k holding the k-th. Near the stack capacity fall back
+        // to one node per round (plain depth-first: the stack then grows by at most the
+        // remaining tree depth).
         const int np = (sp > BPG_STACK - 192) ? 1 : (sp < 64 ? sp : 64);
-        if (lane < np) {
-            stage[lane] = q.tn[no + stack[sp - 1 - lane]];
-        }
+        const std::int32_t my_node = (lane < np) ? stack[sp - 1 - lane] : 0;
         sp -= np;
-#ifdef BPG_DEBUG_STATS
-        if (lane == 0) {
-            atomicAdd(q.counter + 2, (unsigned long long)np);
-            atomicAdd(q.counter + 4, 1ull);
-        }
-#endif
         __syncthreads();
         for (int k = 0; k < np; ++k) {
-            const tnode &t = stage[k];
-            const int4 c0 = t.c0, c1 = t.c1;
-            const bool h0 = bp_overlap(plb, pub, t.lb0, t.ub0), h1 = bp_overlap(plb, pub, t.lb1, t.ub1);
+            const std::int32_t node = __builtin_amdgcn_readlane(my_node, k);
+            const tnode *t = tn + node; // wave-uniform address
+            const float4 lb0 = t->lb0, ub0 = t->ub0, lb1 = t->lb1, ub1 = t->ub1;
+            const int4 c0 = t->c0, c1 = t->c1;
+            const bool h0 = bp_overlap(plb, pub, lb0, ub0), h1 = bp_overlap(plb, pub, lb1, ub1);
             const bool any0 = __ballot(h0) != 0ull, any1 = __ballot(h1) != 0ull;
             if (any0) {
                 if (c0.x >= 0) {
@@ -541,7 +539,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
                     }
                     ++sp;
                 } else {
-                    leaf(h0, c0);
+                    leaf(h0, c0.x, c0.y, c0.z, c0.w);
                 }
             }
             if (any1) {
@@ -551,7 +549,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(bp_params q)
                     }
                     ++sp;
                 } else {
-                    leaf(h1, c1);
+                    leaf(h1, c1.x, c1.y, c1.z, c1.w);
                 }
             }
         }
