@@ -25,6 +25,26 @@ namespace csc
 #define CSC_DEV __device__ __forceinline__
 #define CSC_DEV_NOINLINE __device__ __noinline__
 
+// MI355X: 8 XCDs, each with its own L2; the dispatcher deals workgroups to XCDs round-robin
+// by linear workgroup id. Kernels whose neighbouring workgroups share data (tree nodes,
+// Taylor rows of Morton neighbours) remap the hardware id so that every XCD works on runs of
+// CH consecutive logical workgroups (its L2 then sees the reuse), while the runs themselves
+// stay interleaved across the XCDs (so that dense and sparse regions of the population are
+// spread evenly). The ragged tail keeps the identity mapping.
+#ifndef CSC_XCD_RUN
+#define CSC_XCD_RUN 16
+#endif
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb)
+{
+    constexpr unsigned NXCD = 8, CH = CSC_XCD_RUN, SPAN = NXCD * CH;
+    const unsigned full = (nb / SPAN) * SPAN;
+    if (b >= full) {
+        return b;
+    }
+    const unsigned span = b / SPAN, r = b % SPAN;
+    return span * SPAN + (r % NXCD) * CH + r / NXCD;
+}
+
 // std::min / std::max semantics (NOT fmin/fmax): (b < a) ? b : a.
 CSC_DEV double dmin(double a, double b)
 {

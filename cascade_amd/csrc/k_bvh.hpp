@@ -434,9 +434,11 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
 {
     __shared__ std::int32_t stack[BPG_STACK];
     __shared__ uint2 pairq[BPG_PAIRQ];
-    const std::uint32_t c = blockIdx.y;
+    // Chunk-major linear id, remapped so that each XCD walks one contiguous range of queries.
+    const std::uint32_t lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const std::uint32_t c = lin / gridDim.x;
     const int lane = threadIdx.x;
-    const std::uint32_t pidx = blockIdx.x * 64u + lane;
+    const std::uint32_t pidx = (lin % gridDim.x) * 64u + lane;
     const bool valid = pidx < q.n;
     const std::size_t po = static_cast<std::size_t>(c) * q.n;
     const std::size_t no = static_cast<std::size_t>(c) * q.nn_max;

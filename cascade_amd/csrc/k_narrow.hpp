@@ -1,10 +1,15 @@
 // cascade_amd/csrc/k_narrow.hpp
 //
-// K7: narrow phase. One lane per broad-phase pair; for every overlapping pair of substeps
-// inside the chunk the lane translates the x/y/z Taylor polynomials to a common origin,
-// builds the distance-square polynomial in registers and runs the fast exclusion check.
-// Only if that fails to exclude the interval does the lane enter the (rare, divergent)
-// root isolation + TOMS748 refinement. K8: dense output (Horner of the 6 coordinates).
+// K7: narrow phase, two kernels.
+//   k_np_fex   one lane per broad-phase pair; for every overlapping pair of substeps inside
+//              the chunk the lane translates the x/y/z Taylor polynomials to a common origin,
+//              builds the distance-square polynomial in registers and runs the fast exclusion
+//              checks. Intervals that are NOT excluded (rare) are appended to a survivor list.
+//   k_np_roots one lane per survivor: rebuilds the same polynomial (same operations, same
+//              bits) and runs root isolation + TOMS748 refinement, recording collisions and
+//              conjunctions. Keeping this divergent, register-hungry code out of the first
+//              kernel is what lets the hot kernel run at a useful occupancy.
+// K8: dense output (Horner of the 6 coordinates).
 //
 // Replaces:
 //   src/sim_narrow_phase.cpp:495-1023  narrow_phase_parallel
@@ -54,7 +59,9 @@ struct np_params {
     coll_rec *coll;
     conj_rec *conj;
     std::uint32_t coll_cap, conj_cap;
-    std::uint32_t *counters; // [0] n_coll, [1] n_conj, [2] warnings, [3] n slow-path entries
+    uint4 *surv;             // [surv_cap][2] {pi, pj, chunk, flags} {it_i, it_j, 0, 0}; flags bit0 coll, bit1 conj
+    std::uint32_t surv_cap;
+    std::uint32_t *counters; // [0] n_coll, [1] n_conj, [2] warnings, [3] n survivors
 };
 
 CSC_DEV dfl load_tcoord(const double *tcoords, std::uint64_t row)
@@ -208,7 +215,6 @@ CSC_DEV_NOINLINE void np_slow_path(const np_params &q, const double *ss_in, bool
         ss[o] = ss_in[o];
     }
     int warn = 0;
-    atomicAdd(&q.counters[3], 1u);
     if (do_coll) {
         const double c0 = ss[0];
         ss[0] = c0 - rsum2;
@@ -276,10 +282,78 @@ CSC_DEV_NOINLINE void np_slow_path(const np_params &q, const double *ss_in, bool
     }
 }
 
-template <int P>
-__global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
+// Root-finding window of one pair of substeps (src/sim_narrow_phase.cpp:691-716).
+struct np_window {
+    dfl lb_rf;
+    double delta_i, delta_j, rf_int;
+    dfl tend_i, tend_j;
+    bool ok;
+};
+
+CSC_DEV np_window np_make_window(const np_params &q, dfl chunk_begin, dfl chunk_end, std::uint64_t off_i,
+                                 std::uint32_t it_i, std::uint64_t off_j, std::uint32_t it_j)
 {
-    const std::uint64_t k = static_cast<std::uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    np_window w;
+    const dfl ss_start_i = (it_i == 0u) ? df(0.) : load_tcoord(q.tcoords, off_i + it_i - 1u);
+    const dfl ss_start_j = (it_j == 0u) ? df(0.) : load_tcoord(q.tcoords, off_j + it_j - 1u);
+    w.tend_i = load_tcoord(q.tcoords, off_i + it_i);
+    w.tend_j = load_tcoord(q.tcoords, off_j + it_j);
+    const dfl lb_i = df_max(chunk_begin, ss_start_i), ub_i = df_min(chunk_end, w.tend_i);
+    const dfl lb_j = df_max(chunk_begin, ss_start_j), ub_j = df_min(chunk_end, w.tend_j);
+    const dfl ub_rf = df_min(ub_i, ub_j);
+    w.lb_rf = df_max(lb_i, lb_j);
+    w.delta_i = df_sub(w.lb_rf, ss_start_i).hi;
+    w.delta_j = df_sub(w.lb_rf, ss_start_j).hi;
+    w.rf_int = df_sub(ub_rf, w.lb_rf).hi;
+    w.ok = finite_d(w.delta_i) && finite_d(w.delta_j) && finite_d(w.rf_int) && !(w.delta_i < 0) && !(w.delta_j < 0)
+           && !(w.rf_int < 0);
+    return w;
+}
+
+// Distance-square polynomial (ssdiff3, src/sim_jit.cpp:118-218), coordinate by coordinate.
+template <int P>
+CSC_DEV void np_build_ss(double *ss, const double *xyz, std::uint64_t row_i, std::uint64_t row_j, double delta_i,
+                         double delta_j)
+{
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        double d[P + 1];
+        {
+            double a[P + 1], b[P + 1];
+            load_poly<P>(a, xyz, row_i, cc, delta_i);
+            load_poly<P>(b, xyz, row_j, cc, delta_j);
+#pragma unroll
+            for (int o = 0; o <= P; ++o) {
+                d[o] = a[o] - b[o];
+            }
+        }
+        double sq[P + 1];
+        sq_all<P, 0>::run(sq, d);
+#pragma unroll
+        for (int o = 0; o <= P; ++o) {
+            ss[o] = (cc == 0) ? sq[o] : ss[o] + sq[o];
+        }
+    }
+}
+
+CSC_DEV dfl np_chunk_begin(const np_params &q, std::uint32_t c)
+{
+    return df(q.ct * static_cast<double>(c));
+}
+// get_chunk_begin_end (src/sim_basic.cpp:87-103)
+CSC_DEV dfl np_chunk_end(const np_params &q, std::uint32_t c)
+{
+    return df((c == q.nchunks - 1u) ? q.delta_t : q.ct * static_cast<double>(c + 1u));
+}
+
+#ifndef CSC_NP_WAVES
+#define CSC_NP_WAVES 1
+#endif
+template <int P>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CSC_NP_WAVES, CSC_NP_WAVES))) void k_np_fex(const np_params q)
+{
+    // Consecutive pairs share Taylor rows (the list is grouped by 64 Morton-consecutive queries).
+    const std::uint64_t k = static_cast<std::uint64_t>(xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (k >= q.npairs) {
         return;
     }
@@ -291,13 +365,13 @@ __global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
     }
     const std::uint8_t ai = q.active[pi], aj = q.active[pj];
     const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
-    const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
-    const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
-    const double rsum2 = (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
-
-    // get_chunk_begin_end (src/sim_basic.cpp:87-103)
-    const dfl chunk_begin = df(q.ct * static_cast<double>(c));
-    const dfl chunk_end = df((c == q.nchunks - 1u) ? q.delta_t : q.ct * static_cast<double>(c + 1u));
+    double rsum2 = 0;
+    if (coll_act) {
+        const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
+        const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
+        rsum2 = (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
+    }
+    const dfl chunk_begin = np_chunk_begin(q, c), chunk_end = np_chunk_end(q, c);
 
     const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
     const std::uint32_t ns_i = q.nsub[pi], ns_j = q.nsub[pj];
@@ -306,82 +380,76 @@ __global__ __launch_bounds__(64) void k_narrow_phase(const np_params q)
     substep_range(q.tcoords, off_j, ns_j, chunk_begin, chunk_end, it_j, end_j);
 
     while (it_i != end_i && it_j != end_j) {
-        const dfl ss_start_i = (it_i == 0u) ? df(0.) : load_tcoord(q.tcoords, off_i + it_i - 1u);
-        const dfl ss_start_j = (it_j == 0u) ? df(0.) : load_tcoord(q.tcoords, off_j + it_j - 1u);
-        const dfl tend_i = load_tcoord(q.tcoords, off_i + it_i);
-        const dfl tend_j = load_tcoord(q.tcoords, off_j + it_j);
-        const dfl lb_i = df_max(chunk_begin, ss_start_i), ub_i = df_min(chunk_end, tend_i);
-        const dfl lb_j = df_max(chunk_begin, ss_start_j), ub_j = df_min(chunk_end, tend_j);
-        const dfl lb_rf = df_max(lb_i, lb_j), ub_rf = df_min(ub_i, ub_j);
-        const double delta_i = df_sub(lb_rf, ss_start_i).hi;
-        const double delta_j = df_sub(lb_rf, ss_start_j).hi;
-        const double rf_int = df_sub(ub_rf, lb_rf).hi;
-
-        if (!finite_d(delta_i) || !finite_d(delta_j) || !finite_d(rf_int) || delta_i < 0 || delta_j < 0
-            || rf_int < 0) {
+        const np_window w = np_make_window(q, chunk_begin, chunk_end, off_i, it_i, off_j, it_j);
+        if (!w.ok) {
             atomicOr(&q.counters[2], 16u);
             break;
         }
-
-        // Distance-square polynomial (ssdiff3, src/sim_jit.cpp:118-218), coordinate by coordinate.
         double ss[P + 1];
-        {
-            double a[P + 1], b[P + 1], d[P + 1], sq[P + 1];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                load_poly<P>(a, q.tcs_xyz, off_i + it_i, cc, delta_i);
-                load_poly<P>(b, q.tcs_xyz, off_j + it_j, cc, delta_j);
-#pragma unroll
-                for (int o = 0; o <= P; ++o) {
-                    d[o] = a[o] - b[o];
-                }
-                sq_all<P, 0>::run(sq, d);
-#pragma unroll
-                for (int o = 0; o <= P; ++o) {
-                    ss[o] = (cc == 0) ? sq[o] : ss[o] + sq[o];
-                }
-            }
-        }
+        np_build_ss<P>(ss, q.tcs_xyz, off_i + it_i, off_j + it_j, w.delta_i, w.delta_j);
 
         bool need_coll = false, need_conj = false, bail = false;
         if (coll_act) {
             const double c0 = ss[0];
             ss[0] = c0 - rsum2;
-            need_coll = !fex_excluded<P>(ss, rf_int);
+            need_coll = !fex_excluded<P>(ss, w.rf_int);
             ss[0] = c0;
         }
         if (conj_act) {
-            const ivl d2 = iv_poly_eval<P>(ss, ivl{0., rf_int});
+            const ivl d2 = iv_poly_eval<P>(ss, ivl{0., w.rf_int});
             if (!finite_d(d2.lo) || !finite_d(d2.hi)) {
                 atomicOr(&q.counters[2], 32u);
                 bail = true;
             } else if (d2.lo < q.conj_thresh2) {
-                double der[P + 1];
 #pragma unroll
                 for (int o = 0; o < P; ++o) {
-                    der[o] = (o + 1) * ss[o + 1];
+                    ss[o] = (o + 1) * ss[o + 1];
                 }
-                der[P] = 0;
-                need_conj = !fex_excluded<P>(der, rf_int);
+                ss[P] = 0;
+                need_conj = !fex_excluded<P>(ss, w.rf_int);
             }
         }
         if (need_coll || (need_conj && !bail)) {
-            np_slow_path<P>(q, ss, need_coll, need_conj && !bail, rsum2, rf_int, lb_rf, pi, pj, off_i + it_i,
-                            off_j + it_j, delta_i, delta_j);
+            const std::uint32_t slot = atomicAdd(&q.counters[3], 1u);
+            if (slot < q.surv_cap) {
+                q.surv[2u * slot] = make_uint4(pi, pj, c, (need_coll ? 1u : 0u) | ((need_conj && !bail) ? 2u : 0u));
+                q.surv[2u * slot + 1u] = make_uint4(it_i, it_j, 0u, 0u);
+            }
         }
         if (bail) {
             break;
         }
-
-        if (df_lt(tend_i, tend_j)) {
+        if (df_lt(w.tend_i, w.tend_j)) {
             ++it_i;
-        } else if (df_lt(tend_j, tend_i)) {
+        } else if (df_lt(w.tend_j, w.tend_i)) {
             ++it_j;
         } else {
             ++it_i;
             ++it_j;
         }
     }
+}
+
+// One lane per survivor of k_np_fex: same window, same polynomial, then the root finding.
+template <int P>
+__global__ __launch_bounds__(64) void k_np_roots(const np_params q)
+{
+    const std::uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const std::uint32_t ns = q.counters[3] < q.surv_cap ? q.counters[3] : q.surv_cap;
+    if (k >= ns) {
+        return;
+    }
+    const uint4 r0 = q.surv[2u * k], r1 = q.surv[2u * k + 1u];
+    const std::uint32_t pi = r0.x, pj = r0.y, c = r0.z;
+    const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
+    const np_window w = np_make_window(q, np_chunk_begin(q, c), np_chunk_end(q, c), off_i, r1.x, off_j, r1.y);
+    const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
+    const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
+    const double rsum2 = (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
+    double ss[P + 1];
+    np_build_ss<P>(ss, q.tcs_xyz, off_i + r1.x, off_j + r1.y, w.delta_i, w.delta_j);
+    np_slow_path<P>(q, ss, (r0.w & 1u) != 0, (r0.w & 2u) != 0, rsum2, w.rf_int, w.lb_rf, pi, pj, off_i + r1.x,
+                    off_j + r1.y, w.delta_i, w.delta_j);
 }
 
 // K8: dense_propagate (src/sim_propagate.cpp:1401-1500). out: [n][6].
