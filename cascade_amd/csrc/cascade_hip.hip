@@ -1000,16 +1000,18 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
     if (npairs == 0) {
         return CSC_OK;
     }
-    CSC_BUF(d_cnt, uint32_t, "np_counters", 4);
+    CSC_BUF(d_cnt, uint32_t, "np_counters", 8);
     uint32_t coll_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_coll"].cap / sizeof(csc::coll_rec), 4096));
     uint32_t conj_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_conj"].cap / sizeof(csc::conj_rec), 4096));
     uint32_t surv_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_surv"].cap / (2 * sizeof(uint4)), 65536));
-    uint32_t h[4];
+    uint32_t defer_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_defer"].cap / (2 * sizeof(uint4)), 65536));
+    uint32_t h[8];
     for (int attempt = 0; attempt < 4; ++attempt) {
         CSC_BUF(d_coll, csc::coll_rec, "np_coll", coll_cap);
         CSC_BUF(d_conj, csc::conj_rec, "np_conj", conj_cap);
         CSC_BUF(d_surv, uint4, "np_surv", static_cast<size_t>(surv_cap) * 2u);
-        CSC_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+        CSC_BUF(d_defer, uint4, "np_defer", static_cast<size_t>(defer_cap) * 2u);
+        CSC_HIP(hipMemsetAsync(d_cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
         csc::np_params q{};
         q.n = n;
         q.nchunks = nchunks;
@@ -1033,16 +1035,20 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.conj_cap = conj_cap;
         q.surv = d_surv;
         q.surv_cap = surv_cap;
+        q.defer = d_defer;
+        q.defer_cap = defer_cap;
         q.counters = d_cnt;
-        // Fast exclusion over all pairs, then root finding over the survivors. The second grid
-        // covers the survivor capacity; lanes beyond the device-side count exit at once.
+        // Fast exclusion over all pairs (windows that need a polynomial translation in a second
+        // kernel), then root finding over the survivors. The grids of the follow-up kernels cover
+        // the list capacities; lanes beyond the device-side counts exit at once.
         KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(cdiv(npairs, 64)), dim3(64), 0, ctx->stream, q));
+        KT("k_np_fex_tr", hipLaunchKernelGGL((csc::k_np_fex_tr<20>), dim3(cdiv(defer_cap, 64)), dim3(64), 0, ctx->stream, q));
         const unsigned rg = cdiv(std::min<uint64_t>(surv_cap, npairs * 64u), 64);
         KT("k_np_roots", hipLaunchKernelGGL((csc::k_np_roots<20>), dim3(rg), dim3(64), 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
-        if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap) {
+        if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap) {
             ctx->coll.resize(h[0]);
             ctx->conj.resize(h[1]);
             if (h[0]) {
@@ -1072,6 +1078,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         coll_cap = std::max(coll_cap, h[0] + h[0] / 4u + 16u);
         conj_cap = std::max(conj_cap, h[1] + h[1] / 4u + 16u);
         surv_cap = std::max(surv_cap, h[3] + h[3] / 4u + 16u);
+        defer_cap = std::max(defer_cap, h[4] + h[4] / 4u + 16u);
     }
     ctx->err = "narrow phase output overflow";
     return CSC_ERR_OVERFLOW;

@@ -61,7 +61,9 @@ struct np_params {
     std::uint32_t coll_cap, conj_cap;
     uint4 *surv;             // [surv_cap][2] {pi, pj, chunk, flags} {it_i, it_j, 0, 0}; flags bit0 coll, bit1 conj
     std::uint32_t surv_cap;
-    std::uint32_t *counters; // [0] n_coll, [1] n_conj, [2] warnings, [3] n survivors
+    uint4 *defer;            // [defer_cap][2] windows that need a polynomial translation (same record, flags 0)
+    std::uint32_t defer_cap;
+    std::uint32_t *counters; // [0] n_coll, [1] n_conj, [2] warnings, [3] n survivors, [4] n deferred windows
 };
 
 CSC_DEV dfl load_tcoord(const double *tcoords, std::uint64_t row)
@@ -162,7 +164,7 @@ struct sq_all {
 
 // Loads coordinate c (0..2) of row `row`, translated by delta when delta != 0. The row is
 // 16-byte aligned: 128-bit loads, indices resolved at compile time once c is unrolled.
-template <int P>
+template <int P, bool TR = true>
 CSC_DEV void load_poly(double *out, const double *xyz, std::uint64_t row, int c, double delta)
 {
     const double2 *src = reinterpret_cast<const double2 *>(xyz + row * static_cast<std::uint64_t>(tc_xyz_stride(P)));
@@ -174,13 +176,15 @@ CSC_DEV void load_poly(double *out, const double *xyz, std::uint64_t row, int c,
         const double2 v = src[e >> 1];
         tmp[o] = (e & 1) ? v.y : v.x;
     }
-    if (delta != 0.) {
-        translate_a_regs<P>(out, tmp, delta);
-    } else {
-#pragma unroll
-        for (int o = 0; o <= P; ++o) {
-            out[o] = tmp[o];
+    if constexpr (TR) {
+        if (delta != 0.) {
+            translate_a_regs<P>(out, tmp, delta);
+            return;
         }
+    }
+#pragma unroll
+    for (int o = 0; o <= P; ++o) {
+        out[o] = tmp[o];
     }
 }
 
@@ -311,7 +315,7 @@ CSC_DEV np_window np_make_window(const np_params &q, dfl chunk_begin, dfl chunk_
 }
 
 // Distance-square polynomial (ssdiff3, src/sim_jit.cpp:118-218), coordinate by coordinate.
-template <int P>
+template <int P, bool TR = true>
 CSC_DEV void np_build_ss(double *ss, const double *xyz, std::uint64_t row_i, std::uint64_t row_j, double delta_i,
                          double delta_j)
 {
@@ -320,8 +324,8 @@ CSC_DEV void np_build_ss(double *ss, const double *xyz, std::uint64_t row_i, std
         double d[P + 1];
         {
             double a[P + 1], b[P + 1];
-            load_poly<P>(a, xyz, row_i, cc, delta_i);
-            load_poly<P>(b, xyz, row_j, cc, delta_j);
+            load_poly<P, TR>(a, xyz, row_i, cc, delta_i);
+            load_poly<P, TR>(b, xyz, row_j, cc, delta_j);
 #pragma unroll
             for (int o = 0; o <= P; ++o) {
                 d[o] = a[o] - b[o];
@@ -346,11 +350,57 @@ CSC_DEV dfl np_chunk_end(const np_params &q, std::uint32_t c)
     return df((c == q.nchunks - 1u) ? q.delta_t : q.ct * static_cast<double>(c + 1u));
 }
 
-#ifndef CSC_NP_WAVES
-#define CSC_NP_WAVES 1
-#endif
+// The fast exclusion checks on one window, given its distance-square polynomial (clobbered).
+// Windows that are not excluded are appended to the survivor list. Returns false if the pair
+// must be abandoned (non-finite interval evaluation, src/sim_narrow_phase.cpp:845-852).
 template <int P>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CSC_NP_WAVES, CSC_NP_WAVES))) void k_np_fex(const np_params q)
+CSC_DEV bool np_check_window(const np_params &q, double *ss, bool coll_act, bool conj_act, double rsum2, double rf_int,
+                             std::uint32_t pi, std::uint32_t pj, std::uint32_t c, std::uint32_t it_i, std::uint32_t it_j)
+{
+    bool need_coll = false, need_conj = false, bail = false;
+    if (coll_act) {
+        const double c0 = ss[0];
+        ss[0] = c0 - rsum2;
+        need_coll = !fex_excluded<P>(ss, rf_int);
+        ss[0] = c0;
+    }
+    if (conj_act) {
+        const ivl d2 = iv_poly_eval<P>(ss, ivl{0., rf_int});
+        if (!finite_d(d2.lo) || !finite_d(d2.hi)) {
+            atomicOr(&q.counters[2], 32u);
+            bail = true;
+        } else if (d2.lo < q.conj_thresh2) {
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                ss[o] = (o + 1) * ss[o + 1];
+            }
+            ss[P] = 0;
+            need_conj = !fex_excluded<P>(ss, rf_int);
+        }
+    }
+    if (need_coll || (need_conj && !bail)) {
+        const std::uint32_t slot = atomicAdd(&q.counters[3], 1u);
+        if (slot < q.surv_cap) {
+            q.surv[2u * slot] = make_uint4(pi, pj, c, (need_coll ? 1u : 0u) | ((need_conj && !bail) ? 2u : 0u));
+            q.surv[2u * slot + 1u] = make_uint4(it_i, it_j, 0u, 0u);
+        }
+    }
+    return !bail;
+}
+
+CSC_DEV double np_rsum2(const np_params &q, std::uint32_t pi, std::uint32_t pj)
+{
+    const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
+    const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
+    return (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
+}
+
+// One lane per pair. Windows whose two substeps both start at the window start (no polynomial
+// translation: always the case when every particle takes a single substep per superstep) are
+// checked here; the others are deferred to k_np_fex_tr, whose translation code needs twice the
+// registers, so that this kernel keeps a useful occupancy.
+template <int P>
+__global__ __launch_bounds__(64) void k_np_fex(const np_params q)
 {
     // Consecutive pairs share Taylor rows (the list is grouped by 64 Morton-consecutive queries).
     const std::uint64_t k = static_cast<std::uint64_t>(xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
@@ -365,12 +415,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CSC_NP_WAVES
     }
     const std::uint8_t ai = q.active[pi], aj = q.active[pj];
     const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
-    double rsum2 = 0;
-    if (coll_act) {
-        const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
-        const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
-        rsum2 = (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
-    }
+    const double rsum2 = coll_act ? np_rsum2(q, pi, pj) : 0.;
     const dfl chunk_begin = np_chunk_begin(q, c), chunk_end = np_chunk_end(q, c);
 
     const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
@@ -385,39 +430,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CSC_NP_WAVES
             atomicOr(&q.counters[2], 16u);
             break;
         }
-        double ss[P + 1];
-        np_build_ss<P>(ss, q.tcs_xyz, off_i + it_i, off_j + it_j, w.delta_i, w.delta_j);
-
-        bool need_coll = false, need_conj = false, bail = false;
-        if (coll_act) {
-            const double c0 = ss[0];
-            ss[0] = c0 - rsum2;
-            need_coll = !fex_excluded<P>(ss, w.rf_int);
-            ss[0] = c0;
-        }
-        if (conj_act) {
-            const ivl d2 = iv_poly_eval<P>(ss, ivl{0., w.rf_int});
-            if (!finite_d(d2.lo) || !finite_d(d2.hi)) {
-                atomicOr(&q.counters[2], 32u);
-                bail = true;
-            } else if (d2.lo < q.conj_thresh2) {
-#pragma unroll
-                for (int o = 0; o < P; ++o) {
-                    ss[o] = (o + 1) * ss[o + 1];
-                }
-                ss[P] = 0;
-                need_conj = !fex_excluded<P>(ss, w.rf_int);
+        if (w.delta_i != 0. || w.delta_j != 0.) {
+            const std::uint32_t slot = atomicAdd(&q.counters[4], 1u);
+            if (slot < q.defer_cap) {
+                q.defer[2u * slot] = make_uint4(pi, pj, c, 0u);
+                q.defer[2u * slot + 1u] = make_uint4(it_i, it_j, 0u, 0u);
             }
-        }
-        if (need_coll || (need_conj && !bail)) {
-            const std::uint32_t slot = atomicAdd(&q.counters[3], 1u);
-            if (slot < q.surv_cap) {
-                q.surv[2u * slot] = make_uint4(pi, pj, c, (need_coll ? 1u : 0u) | ((need_conj && !bail) ? 2u : 0u));
-                q.surv[2u * slot + 1u] = make_uint4(it_i, it_j, 0u, 0u);
+        } else {
+            double ss[P + 1];
+            np_build_ss<P, false>(ss, q.tcs_xyz, off_i + it_i, off_j + it_j, 0., 0.);
+            if (!np_check_window<P>(q, ss, coll_act, conj_act, rsum2, w.rf_int, pi, pj, c, it_i, it_j)) {
+                break;
             }
-        }
-        if (bail) {
-            break;
         }
         if (df_lt(w.tend_i, w.tend_j)) {
             ++it_i;
@@ -428,6 +452,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CSC_NP_WAVES
             ++it_j;
         }
     }
+}
+
+// One lane per deferred window (at least one of the two polynomials needs a translation).
+// NOTE: a pair whose window hits the non-finite bail-out is abandoned by the reference for the
+// rest of the chunk; here only that window is dropped (the warning flag is raised either way).
+template <int P>
+__global__ __launch_bounds__(64) void k_np_fex_tr(const np_params q)
+{
+    const std::uint32_t k = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const std::uint32_t nd = q.counters[4] < q.defer_cap ? q.counters[4] : q.defer_cap;
+    if (k >= nd) {
+        return;
+    }
+    const uint4 r0 = q.defer[2u * k], r1 = q.defer[2u * k + 1u];
+    const std::uint32_t pi = r0.x, pj = r0.y, c = r0.z;
+    const std::uint8_t ai = q.active[pi], aj = q.active[pj];
+    const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
+    const double rsum2 = coll_act ? np_rsum2(q, pi, pj) : 0.;
+    const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
+    const np_window w = np_make_window(q, np_chunk_begin(q, c), np_chunk_end(q, c), off_i, r1.x, off_j, r1.y);
+    double ss[P + 1];
+    np_build_ss<P, true>(ss, q.tcs_xyz, off_i + r1.x, off_j + r1.y, w.delta_i, w.delta_j);
+    np_check_window<P>(q, ss, coll_act, conj_act, rsum2, w.rf_int, pi, pj, c, r1.x, r1.y);
 }
 
 // One lane per survivor of k_np_fex: same window, same polynomial, then the root finding.
@@ -443,9 +490,7 @@ __global__ __launch_bounds__(64) void k_np_roots(const np_params q)
     const std::uint32_t pi = r0.x, pj = r0.y, c = r0.z;
     const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
     const np_window w = np_make_window(q, np_chunk_begin(q, c), np_chunk_end(q, c), off_i, r1.x, off_j, r1.y);
-    const double p_rad_i = q.state[static_cast<std::uint64_t>(pi) * 7u + 6u];
-    const double p_rad_j = q.state[static_cast<std::uint64_t>(pj) * 7u + 6u];
-    const double rsum2 = (p_rad_i + p_rad_j) * (p_rad_i + p_rad_j);
+    const double rsum2 = np_rsum2(q, pi, pj);
     double ss[P + 1];
     np_build_ss<P>(ss, q.tcs_xyz, off_i + r1.x, off_j + r1.y, w.delta_i, w.delta_j);
     np_slow_path<P>(q, ss, (r0.w & 1u) != 0, (r0.w & 2u) != 0, rsum2, w.rf_int, w.lb_rf, pi, pj, off_i + r1.x,
