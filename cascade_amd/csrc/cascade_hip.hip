@@ -700,15 +700,16 @@ static int radix_sort(csc_ctx *ctx, uint32_t n, uint32_t nseg, int nbits, uint64
 {
     const unsigned nblocks = cdiv(n, csc::RS_TILE);
     CSC_BUF(d_hist, uint32_t, "rs_hist", static_cast<size_t>(nseg) * csc::RS_BINS * nblocks);
+    CSC_BUF(d_btot, uint32_t, "rs_bin_tot", static_cast<size_t>(nseg) * csc::RS_BINS);
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
     bool iota = vals_iota;
     for (int shift = 0; shift < nbits; shift += 8) {
         KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin, n, shift,
                            d_hist, nblocks));
-        KT("k_rs_scan", hipLaunchKernelGGL(csc::k_rs_scan, dim3(nseg), dim3(1024), 0, ctx->stream, d_hist, nblocks));
+        KT("k_rs_scan", hipLaunchKernelGGL(csc::k_rs_scan, dim3(csc::RS_BINS, nseg), dim3(256), 0, ctx->stream, d_hist, nblocks, d_btot));
         KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
-                           iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks));
+                           iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
         CSC_LAUNCH_CHECK();
         std::swap(kin, kout);
         std::swap(vin, vout);
@@ -788,6 +789,7 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     BB(new_of, uint32_t, cnn)
     BB(level_cnt, uint32_t, static_cast<size_t>(nchunks) * csc::BVH_MAX_LEVELS)
     BB(level_off, uint32_t, static_cast<size_t>(nchunks) * (csc::BVH_MAX_LEVELS + 1))
+    BB(visit, uint32_t, cnn)
     BB(nb, uint32_t, cnn)
     BB(ne, uint32_t, cnn)
     BB(npar, int32_t, cnn)
@@ -819,11 +821,9 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     }
     KT("k_bvh_newidx", hipLaunchKernelGGL(csc::k_bvh_newidx, gn, blk, 0, ctx->stream, b, vres));
     KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit, gn, blk, 0, ctx->stream, b, vres));
-    // Bottom-up refit, one launch per level (children are final when their level is done).
-    const unsigned rg = std::min(cdiv(nn_max, 256), 1024u);
-    for (int level = csc::BVH_MAX_LEVELS - 2; level >= 0; --level) {
-        KT("k_bvh_refit_level", hipLaunchKernelGGL(csc::k_bvh_refit_level, dim3(rg, nchunks), blk, 0, ctx->stream, b, level));
-    }
+    // Bottom-up refit in one launch (arrival counters start from zero).
+    CSC_HIP(hipMemsetAsync(b.visit, 0, cnn * sizeof(uint32_t), ctx->stream));
+    KT("k_bvh_refit", hipLaunchKernelGGL(csc::k_bvh_refit, gn, blk, 0, ctx->stream, b));
     CSC_LAUNCH_CHECK();
     ctx->bvh = b;
     ctx->bvh_packed = false;

@@ -50,6 +50,7 @@ struct bvh_bufs {
     std::uint32_t *new_of;    // [C][nn_max]
     std::uint32_t *level_cnt; // [C][BVH_MAX_LEVELS]
     std::uint32_t *level_off; // [C][BVH_MAX_LEVELS + 1]
+    std::uint32_t *visit;     // [C][nn_max] refit arrival counters (zeroed per build)
     // output
     std::uint32_t *nb, *ne;
     std::int32_t *npar, *nleft;
@@ -279,23 +280,52 @@ __global__ __launch_bounds__(256) void k_bvh_emit(bvh_bufs b, const std::uint32_
     b.nsplit[no + p] = split;
 }
 
-// Internal-node AABBs of one level from the (already final) children one level below.
-// Fixed grid, grid-stride over the level; empty levels return at once.
-__global__ __launch_bounds__(256) void k_bvh_refit_level(bvh_bufs b, int level)
+// Internal-node AABBs, bottom-up in ONE launch (replaces the level-by-level loop of
+// src/sim_bvh.cpp:411-485). One thread per leaf climbs towards the root; at every internal
+// node the first arriving child stops, the second one (both subtrees final) forms the union of
+// the two child boxes and goes on. min/max are exact and order-independent, so the boxes are
+// bit-identical to the level-synchronous result. Hand-off between the two children (they may
+// run on different XCDs): the box is written with agent-scope (sc1, write-through) stores, the
+// storing wave waits for them (s_waitcnt vmcnt(0)) and only then bumps the node's counter with
+// an agent-scope atomic; the thread whose add came last reads the child boxes with agent-scope
+// (sc1) loads issued after its add has returned. No cache-wide fence is involved: a
+// __threadfence() here costs an L2 write-back per call (measured: 6 ms instead of 0.05 ms).
+CSC_DEV void st_agent(float *p, float v)
 {
-    const std::uint32_t c = blockIdx.y;
-    const std::uint32_t lo = b.level_off[c * (BVH_MAX_LEVELS + 1) + level];
-    const std::uint32_t hi = b.level_off[c * (BVH_MAX_LEVELS + 1) + level + 1];
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+CSC_DEV float ld_agent(const float *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_bvh_refit(bvh_bufs b)
+{
+    const std::uint32_t c = blockIdx.y, p0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p0 >= b.n_nodes[c]) {
+        return;
+    }
     const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
-    for (std::uint32_t p = lo + blockIdx.x * blockDim.x + threadIdx.x; p < hi; p += gridDim.x * blockDim.x) {
-        const std::int32_t l = b.nleft[no + p];
-        if (l >= 0) {
-            const float4 a = b.nlb[no + l], bb = b.nlb[no + l + 1];
-            const float4 ua = b.nub[no + l], ubb = b.nub[no + l + 1];
-            b.nlb[no + p] = make_float4(fminf_std(a.x, bb.x), fminf_std(a.y, bb.y), fminf_std(a.z, bb.z), fminf_std(a.w, bb.w));
-            b.nub[no + p]
-                = make_float4(fmaxf_std(ua.x, ubb.x), fmaxf_std(ua.y, ubb.y), fmaxf_std(ua.z, ubb.z), fmaxf_std(ua.w, ubb.w));
+    if (b.nleft[no + p0] >= 0) {
+        return; // climbs start at the leaves
+    }
+    std::int32_t cur = b.npar[no + p0];
+    while (cur >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const std::uint32_t arrived = atomicAdd(&b.visit[no + cur], 1u);
+        if (arrived == 0u) {
+            return;
         }
+        asm volatile("" ::: "memory");
+        const std::int32_t l = b.nleft[no + cur];
+        const float *la = reinterpret_cast<const float *>(b.nlb + no + l), *ua = reinterpret_cast<const float *>(b.nub + no + l);
+        float *lo = reinterpret_cast<float *>(b.nlb + no + cur), *uo = reinterpret_cast<float *>(b.nub + no + cur);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st_agent(lo + k, fminf_std(ld_agent(la + k), ld_agent(la + 4 + k)));
+            st_agent(uo + k, fmaxf_std(ld_agent(ua + k), ld_agent(ua + 4 + k)));
+        }
+        cur = b.npar[no + cur];
     }
 }
 

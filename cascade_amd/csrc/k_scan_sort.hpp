@@ -171,42 +171,26 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const std::uint64_t *keys,
     block_hist[(static_cast<std::size_t>(chunk) * RS_BINS + threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// One block per chunk: exclusive scan over RS_BINS * nblocks counters, in place.
-__global__ __launch_bounds__(1024) void k_rs_scan(std::uint32_t *block_hist, std::uint32_t nblocks)
+// One block per (bin, chunk): exclusive scan of that bin's per-block counters in place, bin
+// total to bin_tot[chunk][bin]. 256 independent short scans instead of one long serial one.
+__global__ __launch_bounds__(256) void k_rs_scan(std::uint32_t *block_hist, std::uint32_t nblocks, std::uint32_t *bin_tot)
 {
-    __shared__ std::uint64_t lds[1024 / 64 + 1];
-    __shared__ std::uint32_t carry_s;
-    const std::uint32_t chunk = blockIdx.x;
-    std::uint32_t *h = block_hist + static_cast<std::size_t>(chunk) * RS_BINS * nblocks;
-    const std::uint32_t tot_n = RS_BINS * nblocks;
-    if (threadIdx.x == 0) {
-        carry_s = 0;
-    }
-    __syncthreads();
-    constexpr int PER = 8;
-    for (std::uint32_t start = 0; start < tot_n; start += 1024 * PER) {
-        const std::uint32_t b = start + threadIdx.x * PER;
-        std::uint32_t v[PER];
-        std::uint64_t s = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            v[k] = (b + k < tot_n) ? h[b + k] : 0u;
-            s += v[k];
-        }
+    __shared__ std::uint64_t lds[256 / 64 + 1];
+    const std::uint32_t bin = blockIdx.x, chunk = blockIdx.y;
+    std::uint32_t *h = block_hist + (static_cast<std::size_t>(chunk) * RS_BINS + bin) * nblocks;
+    std::uint32_t carry = 0;
+    for (std::uint32_t start = 0; start < nblocks; start += 256) {
+        const std::uint32_t idx = start + threadIdx.x;
+        const std::uint32_t v = idx < nblocks ? h[idx] : 0u;
         std::uint64_t tot;
-        std::uint32_t ex = static_cast<std::uint32_t>(block_exclusive_scan_u64(s, &tot, lds)) + carry_s;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            if (b + k < tot_n) {
-                h[b + k] = ex;
-            }
-            ex += v[k];
+        const std::uint32_t ex = static_cast<std::uint32_t>(block_exclusive_scan_u64(v, &tot, lds));
+        if (idx < nblocks) {
+            h[idx] = carry + ex;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            carry_s += static_cast<std::uint32_t>(tot);
-        }
-        __syncthreads();
+        carry += static_cast<std::uint32_t>(tot);
+    }
+    if (threadIdx.x == 0) {
+        bin_tot[chunk * RS_BINS + bin] = carry;
     }
 }
 
@@ -214,9 +198,10 @@ __global__ __launch_bounds__(1024) void k_rs_scan(std::uint32_t *block_hist, std
 __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const std::uint64_t *keys_in, const std::uint32_t *vals_in,
                                                          std::uint64_t *keys_out, std::uint32_t *vals_out,
                                                          std::uint32_t n, int shift, const std::uint32_t *block_hist,
-                                                         std::uint32_t nblocks)
+                                                         std::uint32_t nblocks, const std::uint32_t *bin_tot)
 {
     __shared__ std::uint32_t cnt[RS_WAVES][RS_BINS];
+    __shared__ std::uint64_t scan_lds[RS_BLOCK / 64 + 1];
     const std::uint32_t chunk = blockIdx.y;
     const std::size_t coff = static_cast<std::size_t>(chunk) * n;
     keys_in += coff;
@@ -268,7 +253,12 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const std::uint64_t *ke
     // counts of the preceding waves of this block.
     {
         const int d = threadIdx.x; // RS_BLOCK == RS_BINS
-        std::uint32_t run = goff[static_cast<std::size_t>(d) * nblocks + blockIdx.x];
+        // Start of digit d = keys with a smaller digit (scan of the bin totals) + keys with digit d
+        // in earlier blocks.
+        std::uint64_t tot_unused;
+        const std::uint32_t bin_base
+            = static_cast<std::uint32_t>(block_exclusive_scan_u64(bin_tot[chunk * RS_BINS + d], &tot_unused, scan_lds));
+        std::uint32_t run = bin_base + goff[static_cast<std::size_t>(d) * nblocks + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) {
             const std::uint32_t c = cnt[w][d];
