@@ -38,11 +38,28 @@ FP64_VEC_PEAK_TFLOPS = 78.6
 BYTES = {
     "k_propagate_store": lambda u: u["substeps"] * (1176 + 16) + u["n"] * 56,
     "k_propagate": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28),
-    "k_narrow_phase": lambda u: u["pair_intervals"] * 1008,
+    "k_np_fex": lambda u: u["pair_intervals"] * 1008,
     "k_broad_phase": lambda u: u["bp_nodes_visited"] * 44 + u["pairs"] * 8,
     "k_rs_scatter": lambda u: u["sort_keys"] * 24,
     "k_rs_hist": lambda u: u["sort_keys"] * 8,
 }
+
+
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary under profiles/
+    (profiles/summarise.py: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, plus
+    WRITE_SIZE) whose workload string matches this run; None otherwise."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and kernel in d.get("kernels", {}):
+            best = (d["kernels"][kernel]["traffic_bytes"], os.path.basename(path))
+    return best
 
 
 def main():
@@ -131,17 +148,25 @@ def main():
     dom = max(kern, key=lambda k: kern[k][1])
     # Units of the last step (populations change slowly; the counts of all steps agree to <0.1 %).
     units = dict(n=N, nchunks=args.n_par_ct, substeps=s.last_total_substeps, pairs=pairs / args.steps, pair_intervals=pairs / args.steps * max(1.0, s.last_total_substeps / (N * args.n_par_ct)), sort_keys=N * args.n_par_ct, bp_nodes_visited=s.bp_nodes_visited())
-    launches, ms = kern[dom]
-    per_step_launches = launches / args.steps
-    avg_ms = ms / launches
-    roof = None
-    if dom in BYTES:
-        alg_bytes_per_step = BYTES[dom](units)
-        alg_bytes_per_launch = alg_bytes_per_step / per_step_launches
-        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(avg_ms, 5), algorithmic_bytes_per_launch=int(alg_bytes_per_launch), units={k: v for k, v in units.items()})
-    else:
-        roof = dict(bound="hbm", kernel=dom, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, avg_launch_ms=round(avg_ms, 5))
+    workload = "random_leo_pop_kep scaled to %d objects per GPU (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, args.ct, args.n_par_ct)
+
+    def roofline_of(name):
+        launches, ms = kern[name]
+        per_step_launches = launches / args.steps
+        avg_ms = ms / launches
+        r = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, avg_launch_ms=round(avg_ms, 5))
+        if name in BYTES:
+            alg_bytes_per_launch = BYTES[name](units) / per_step_launches
+            achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            r.update(achieved=round(achieved, 2), frac=round(achieved / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(alg_bytes_per_launch))
+        t = measured_traffic(name, workload)
+        if t is not None:
+            r.update(traffic=t[0], traffic_source="profiles/" + t[1], traffic_GBps=round(t[0] / (avg_ms * 1e-3) / 1e9, 1))
+        return r
+
+    roof = roofline_of(dom)
+    roof["units"] = {k: v for k, v in units.items()}
+    other_roofs = [roofline_of(k) for k in sorted(kern, key=lambda k: -kern[k][1])[1:4] if k in BYTES]
 
     out = {
         "metric": "object-days propagated/sec incl. collision detection",
@@ -157,7 +182,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "random_leo_pop_kep scaled to %d objects per GPU (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, args.ct, args.n_par_ct),
+            "workload": workload,
             "nparts_per_gpu": N,
             "ct": args.ct,
             "n_par_ct": args.n_par_ct,
@@ -167,6 +192,7 @@ def main():
             "sim_time_advanced_TU": sim_time,
         },
         "roofline": roof,
+        "roofline_other_kernels": other_roofs,
         "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
         "kernel_ms_total_per_step": round(tot_kernel_ms / args.steps, 4),
     }
