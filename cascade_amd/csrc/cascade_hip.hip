@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -49,7 +50,10 @@ struct csc_ctx {
     uint32_t bvh_n = 0, bvh_chunks = 0;
     bool bvh_packed = false; // wide traversal nodes built for the current trees
     // broad phase state
-    uint64_t bp_total = 0, bp_cap = 0;
+    uint64_t bp_total = 0;
+    uint32_t bp_blocks = 0, bp_cap_per_shard = 0; // pair blocks used / pool capacity
+    csc::pair_lists bp_pl{};
+    const uint2 *bp_order = nullptr; // group-major {block, time chunk} list of the last broad phase
     uint32_t bp_n = 0, bp_chunks = 0;
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
@@ -286,19 +290,15 @@ __global__ __launch_bounds__(256) void k_gather_u32(uint32_t n, const uint32_t *
     }
 }
 
-// Caller-provided [npairs][2] pairs with per-chunk offsets -> {i, j, chunk, 0} records.
-__global__ __launch_bounds__(256) void k_tag_pairs(uint64_t npairs, const uint32_t *pairs, const uint64_t *off,
-                                                   uint32_t nchunks, uint4 *out)
+// Caller-provided [npairs][2] pairs -> pair blocks: block b takes count[b] pairs from src_start[b].
+__global__ __launch_bounds__(256) void k_pack_pairs(const uint32_t *pairs, const uint64_t *src_start, const uint32_t *count,
+                                                    uint2 *out)
 {
-    const uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (k >= npairs) {
-        return;
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (t < count[b]) {
+        const uint64_t k = src_start[b] + t;
+        out[static_cast<size_t>(b) * csc::PB_SIZE + t] = make_uint2(pairs[k * 2u], pairs[k * 2u + 1u]);
     }
-    uint32_t c = 0;
-    while (c + 1u < nchunks && off[c + 1u] <= k) {
-        ++c;
-    }
-    out[k] = make_uint4(pairs[k * 2u], pairs[k * 2u + 1u], c, 0u);
 }
 
 csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const double *d_state)
@@ -881,38 +881,70 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     q.active = d_active;
     q.counter = ctx->d_bp_counter;
     q.err_flag = ctx->d_flags + 2;
-    const dim3 grid(cdiv(n, 64), nchunks), blk(64);
-    // The pair list is appended through a device counter; its capacity follows the last
-    // superstep's count (populations change slowly), and an overflow re-runs the traversal.
-    uint64_t cap = std::max<uint64_t>({ctx->bp_cap, static_cast<uint64_t>(n) * nchunks * 8u, 1u << 16});
-    unsigned long long total = 0;
+    const uint32_t ngroups = cdiv(n, 64);
+    const uint32_t nlists = ngroups * nchunks;
+    const dim3 grid(ngroups, nchunks), blk(64);
+    CSC_BUF(d_head, int32_t, "bp_head", nlists);
+    CSC_BUF(d_nblk, uint32_t, "bp_nblk", nlists);
+    CSC_BUF(d_tchunk, uint32_t, "bp_tchunk", nlists);
+    CSC_BUF(d_off, uint32_t, "bp_list_off", nlists + 1u);
+    CSC_BUF(d_ctr, unsigned long long, "bp_shard_ctr", csc::PL_SHARDS * csc::PL_CTR_STRIDE);
+    // Pair blocks come from per-shard pools; the pool capacity follows the last superstep's use
+    // (populations change slowly), and an overflow re-runs the traversal.
+    uint32_t cap_ps = std::max<uint32_t>({ctx->bp_cap_per_shard, cdiv(nlists * 2u, csc::PL_SHARDS), 64u});
+    std::vector<unsigned long long> hc(csc::PL_SHARDS * csc::PL_CTR_STRIDE);
+    unsigned long long total_pairs = 0, total_blocks = 0, max_local = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        CSC_BUF(d_pairs, uint4, "bp_pairs", cap);
-        q.pairs = d_pairs;
-        q.cap = cap;
-#ifdef BPG_DEBUG_STATS
-        CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, 8 * sizeof(unsigned long long), ctx->stream));
-#else
-        CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, sizeof(unsigned long long), ctx->stream));
-#endif
+        const size_t cap_blocks = static_cast<size_t>(cap_ps) * csc::PL_SHARDS;
+        CSC_BUF(d_pairs, uint2, "bp_pairs", cap_blocks * csc::PB_SIZE);
+        CSC_BUF(d_pbc, uint32_t, "bp_pb_count", cap_blocks);
+        CSC_BUF(d_pbn, int32_t, "bp_pb_next", cap_blocks);
+        q.pl.pairs = d_pairs;
+        q.pl.pb_count = d_pbc;
+        q.pl.pb_next = d_pbn;
+        q.pl.head = d_head;
+        q.pl.nblk = d_nblk;
+        q.pl.tchunk = d_tchunk;
+        q.pl.shard_ctr = d_ctr;
+        q.pl.cap_per_shard = cap_ps;
+        q.pl.nlists = nlists;
+        CSC_HIP(hipMemsetAsync(d_ctr, 0, hc.size() * sizeof(unsigned long long), ctx->stream));
+        CSC_HIP(hipMemsetAsync(d_nblk, 0, nlists * sizeof(uint32_t), ctx->stream));
         KT("k_broad_phase", hipLaunchKernelGGL(csc::k_broad_phase, grid, blk, 0, ctx->stream, static_cast<const csc::tnode *>(d_tn), q));
         CSC_LAUNCH_CHECK();
-        CSC_HIP(hipMemcpyAsync(&total, ctx->d_bp_counter, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(hc.data(), d_ctr, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
-        if (total <= cap) {
+        total_pairs = total_blocks = max_local = 0;
+        for (int sh = 0; sh < csc::PL_SHARDS; ++sh) {
+            const unsigned long long v = hc[static_cast<size_t>(sh) * csc::PL_CTR_STRIDE];
+            total_pairs += v & ((1ull << 40) - 1u);
+            total_blocks += v >> 40;
+            max_local = std::max(max_local, v >> 40);
+        }
+        if (max_local <= cap_ps) {
             break;
         }
-        cap = total + total / 8u;
+        cap_ps = static_cast<uint32_t>(max_local + max_local / 8u + 16u);
     }
-    if (total > cap) {
+    if (max_local > cap_ps) {
         ctx->err = "broad phase pair list overflow";
         return CSC_ERR_OVERFLOW;
     }
-    ctx->bp_cap = std::max<uint64_t>(cap, total + total / 4u);
-    ctx->bp_total = total;
+    // Group-major order of the blocks for the narrow phase.
+    CSC_BUF(d_order, uint2, "bp_order", std::max<unsigned long long>(total_blocks, 1));
+    if (const int rc = scan_impl(ctx, d_nblk, nlists, 1, nullptr, d_off)) {
+        return rc;
+    }
+    KT("k_pl_order", hipLaunchKernelGGL(csc::k_pl_order, dim3(cdiv(nlists, 256)), dim3(256), 0, ctx->stream, q.pl, d_off, d_order));
+    CSC_LAUNCH_CHECK();
+    ctx->bp_cap_per_shard = std::max<uint32_t>(cap_ps, static_cast<uint32_t>(max_local + max_local / 4u + 16u));
+    ctx->bp_total = total_pairs;
+    ctx->bp_blocks = static_cast<uint32_t>(total_blocks);
+    ctx->bp_pl = q.pl;
+    ctx->bp_order = d_order;
     ctx->bp_n = n;
     ctx->bp_chunks = nchunks;
-    *n_pairs = total;
+    *n_pairs = total_pairs;
     return CSC_OK;
 }
 
@@ -945,33 +977,33 @@ int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const floa
     return CSC_OK;
 }
 
-#ifdef BPG_DEBUG_STATS
-int csc_debug_counters(csc_ctx *ctx, unsigned long long *out)
-{
-    CSC_HIP(hipMemcpy(out, ctx->d_bp_counter, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return CSC_OK;
-}
-#endif
-
 int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t cap, uint64_t *count)
 {
     if (chunk >= ctx->bp_chunks) {
         return ctx->invalid("invalid chunk index");
     }
-    std::vector<uint4> h(ctx->bp_total);
-    if (ctx->bp_total) {
-        CSC_HIP(hipMemcpyAsync(h.data(), ctx->bufs["bp_pairs"].p, ctx->bp_total * sizeof(uint4), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    const csc::pair_lists &pl = ctx->bp_pl;
+    const uint32_t nb = ctx->bp_blocks;
+    std::vector<uint2> order(nb);
+    if (nb) {
+        CSC_HIP(hipMemcpyAsync(order.data(), ctx->bp_order, nb * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
     }
     CSC_HIP(hipStreamSynchronize(ctx->stream));
     uint64_t k = 0;
-    for (const auto &r : h) {
-        if (r.z == chunk) {
+    std::vector<uint2> h(csc::PB_SIZE);
+    for (uint32_t e = 0; e < nb; ++e) {
+        if (order[e].y != chunk) {
+            continue;
+        }
+        uint32_t cnt = 0;
+        CSC_HIP(hipMemcpy(&cnt, pl.pb_count + order[e].x, sizeof(cnt), hipMemcpyDeviceToHost));
+        CSC_HIP(hipMemcpy(h.data(), pl.pairs + static_cast<size_t>(order[e].x) * csc::PB_SIZE, cnt * sizeof(uint2),
+                          hipMemcpyDeviceToHost));
+        for (uint32_t t = 0; t < cnt; ++t, ++k) {
             if (k < cap) {
-                pairs[k * 2u] = r.x;
-                pairs[k * 2u + 1u] = r.y;
+                pairs[k * 2u] = h[t].x;
+                pairs[k * 2u + 1u] = h[t].y;
             }
-            ++k;
         }
     }
     *count = k;
@@ -983,8 +1015,9 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
 static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                        double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
                        const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
-                       const double *d_tcs_vr, const double *d_tcoords, const uint4 *d_pairs, uint64_t npairs,
-                       uint64_t *n_coll, uint64_t *n_conj, uint32_t *warn_flags)
+                       const double *d_tcs_vr, const double *d_tcoords, const uint2 *d_order, uint32_t norder,
+                       const uint32_t *d_pb_count, const uint2 *d_pb_pairs, uint64_t npairs, uint64_t *n_coll,
+                       uint64_t *n_conj, uint32_t *warn_flags)
 {
     if (order != 20u) {
         ctx->err = "only Taylor order 20 is built";
@@ -1027,8 +1060,10 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.tcs_xyz = d_tcs_xyz;
         q.tcs_vr = d_tcs_vr;
         q.tcoords = d_tcoords;
-        q.pairs = d_pairs;
-        q.npairs = npairs;
+        q.order = d_order;
+        q.norder = norder;
+        q.pb_count = d_pb_count;
+        q.pairs = d_pb_pairs;
         q.coll = d_coll;
         q.conj = d_conj;
         q.coll_cap = coll_cap;
@@ -1041,9 +1076,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         // Fast exclusion over all pairs (windows that need a polynomial translation in a second
         // kernel), then root finding over the survivors. The grids of the follow-up kernels cover
         // the list capacities; lanes beyond the device-side counts exit at once.
-        KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(cdiv(npairs, 64)), dim3(64), 0, ctx->stream, q));
+        KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(norder * (csc::PB_SIZE / 64)), dim3(64), 0, ctx->stream, q));
         KT("k_np_fex_tr", hipLaunchKernelGGL((csc::k_np_fex_tr<20>), dim3(cdiv(defer_cap, 64)), dim3(64), 0, ctx->stream, q));
-        const unsigned rg = cdiv(std::min<uint64_t>(surv_cap, npairs * 64u), 64);
+        const unsigned rg = cdiv(surv_cap, 64);
         KT("k_np_roots", hipLaunchKernelGGL((csc::k_np_roots<20>), dim3(rg), dim3(64), 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1096,7 +1131,8 @@ int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, doub
     // After a terminal-event shrink the kernel skips the pairs of the dropped chunks.
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
                        d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords,
-                       static_cast<const uint4 *>(ctx->bufs["bp_pairs"].p), ctx->bp_total, n_coll, n_conj, warn_flags);
+                       ctx->bp_order, ctx->bp_blocks, ctx->bp_pl.pb_count, ctx->bp_pl.pairs, ctx->bp_total, n_coll, n_conj,
+                       warn_flags);
 }
 
 int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
@@ -1106,18 +1142,34 @@ int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct
                            const uint32_t *d_pairs, const uint64_t *pair_off, uint64_t *n_coll, uint64_t *n_conj,
                            uint32_t *warn_flags)
 {
+    // One pair block per 256 injected pairs of a chunk.
     const uint64_t npairs = pair_off[nchunks];
-    CSC_BUF(d_off, uint64_t, "np_pair_off", nchunks + 1u);
-    CSC_BUF(d_rec, uint4, "np_pair_rec", std::max<uint64_t>(npairs, 1));
-    CSC_HIP(hipMemcpyAsync(d_off, pair_off, (nchunks + 1u) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    CSC_HIP(hipStreamSynchronize(ctx->stream));
-    if (npairs) {
-        KT("k_tag_pairs", hipLaunchKernelGGL(k_tag_pairs, dim3(cdiv(npairs, 256)), dim3(256), 0, ctx->stream, npairs, d_pairs, d_off,
-                                              nchunks, d_rec));
+    std::vector<uint64_t> src_start;
+    std::vector<uint32_t> count;
+    std::vector<uint2> blk_order;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        for (uint64_t k = pair_off[c]; k < pair_off[c + 1u]; k += csc::PB_SIZE) {
+            blk_order.push_back(make_uint2(static_cast<uint32_t>(count.size()), c));
+            src_start.push_back(k);
+            count.push_back(static_cast<uint32_t>(std::min<uint64_t>(csc::PB_SIZE, pair_off[c + 1u] - k)));
+        }
+    }
+    const uint32_t nb = static_cast<uint32_t>(count.size());
+    CSC_BUF(d_src, uint64_t, "np_inj_src", std::max(nb, 1u));
+    CSC_BUF(d_cnt, uint32_t, "np_inj_count", std::max(nb, 1u));
+    CSC_BUF(d_ord, uint2, "np_inj_order", std::max(nb, 1u));
+    CSC_BUF(d_rec, uint2, "np_inj_pairs", static_cast<size_t>(std::max(nb, 1u)) * csc::PB_SIZE);
+    if (nb) {
+        CSC_HIP(hipMemcpyAsync(d_src, src_start.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(d_cnt, count.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(d_ord, blk_order.data(), nb * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        KT("k_pack_pairs", hipLaunchKernelGGL(k_pack_pairs, dim3(nb), dim3(csc::PB_SIZE), 0, ctx->stream, d_pairs, d_src, d_cnt, d_rec));
         CSC_LAUNCH_CHECK();
+        CSC_HIP(hipStreamSynchronize(ctx->stream)); // the host vectors go out of scope
     }
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
-                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, d_rec, npairs, n_coll, n_conj, warn_flags);
+                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, d_ord, nb, d_cnt, d_rec, npairs, n_coll, n_conj,
+                       warn_flags);
 }
 
 int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,

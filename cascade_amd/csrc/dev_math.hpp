@@ -34,9 +34,10 @@ namespace csc
 #ifndef CSC_XCD_RUN
 #define CSC_XCD_RUN 16
 #endif
+template <unsigned CH = CSC_XCD_RUN>
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb)
 {
-    constexpr unsigned NXCD = 8, CH = CSC_XCD_RUN, SPAN = NXCD * CH;
+    constexpr unsigned NXCD = 8, SPAN = NXCD * CH;
     const unsigned full = (nb / SPAN) * SPAN;
     if (b >= full) {
         return b;

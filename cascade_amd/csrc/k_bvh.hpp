@@ -396,7 +396,6 @@ __global__ __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t ch
 // A child descriptor is {tag, begin, end, orig}: tag = the child's own canonical index when it
 // is internal; for a leaf tag = -1 - act where act is the activity byte of its (first)
 // particle; [begin, end) the particle range; orig the original index of the first particle.
-// Pair record: {i, j, chunk, 0} u32x4.
 // ---------------------------------------------------------------------------
 struct tnode {
     float4 lb0, ub0, lb1, ub1;
@@ -432,6 +431,48 @@ __global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_
     tn[no + p] = t;
 }
 
+// Output of the broad phase: pair blocks of up to PB_SIZE pairs {i, j}. A wave flushes its LDS
+// staging buffer into a freshly allocated block, so every block holds pairs of ONE group of 64
+// Morton-consecutive queries; the blocks of a group are chained (newest first) and k_pl_order
+// then lists all blocks group by group. The narrow phase follows that list, which is what gives
+// its Taylor-row gathers L1/L2 locality (the 64 query rows of a group are contiguous, the
+// partner rows of neighbouring groups largely coincide).
+// Blocks are allocated from PL_SHARDS independent pools (one counter each, on its own cache
+// line): a single device-wide counter serialises ~10^5 atomics per launch at the memory side.
+constexpr int PB_SIZE = 256;
+constexpr int PL_SHARDS = 32;
+constexpr int PL_CTR_STRIDE = 16; // counters are 128 bytes apart
+
+struct pair_lists {
+    uint2 *pairs;            // [cap_blocks][PB_SIZE] {i, j}, i < j
+    std::uint32_t *pb_count; // [cap_blocks] pairs in the block
+    std::int32_t *pb_next;   // [cap_blocks] next block of the same list, -1 = end
+    std::int32_t *head;      // [nlists] first block of the list (valid when nblk > 0)
+    std::uint32_t *nblk;     // [nlists] blocks in the list (zeroed before the launch)
+    std::uint32_t *tchunk;   // [nlists] time chunk of the list
+    unsigned long long *shard_ctr; // [PL_SHARDS][PL_CTR_STRIDE]: blocks allocated << 40 | pairs
+    std::uint32_t cap_per_shard;   // pool s owns blocks [s * cap_per_shard, (s + 1) * cap_per_shard)
+    std::uint32_t nlists;
+};
+
+// Group-major list of the pair blocks: order[off[g] + k] = {k-th block of list g, time chunk}.
+__global__ __launch_bounds__(256) void k_pl_order(pair_lists pl, const std::uint32_t *off, uint2 *order)
+{
+    const std::uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.nlists) {
+        return;
+    }
+    const std::uint32_t nb = pl.nblk[g];
+    if (nb == 0u) {
+        return;
+    }
+    const std::uint32_t c = pl.tchunk[g];
+    std::int32_t b = pl.head[g];
+    for (std::uint32_t k = 0; k < nb && b >= 0; ++k, b = pl.pb_next[b]) {
+        order[off[g] + k] = make_uint2(static_cast<std::uint32_t>(b), c);
+    }
+}
+
 struct bp_params {
     std::uint32_t n;
     std::uint32_t nn_max;
@@ -441,12 +482,26 @@ struct bp_params {
     const float4 *nlb, *nub;     // [C][nn_max] (root box)
     const std::int32_t *nleft;   // root leaf test
     const std::uint8_t *active;  // [n] bit0 coll_active, bit1 conj_active
-    uint4 *pairs;                // [cap] {i, j, chunk, 0}
-    std::uint64_t cap;
-    unsigned long long *counter; // [0] pairs found (may exceed cap: overflow), [1] statistics
+    pair_lists pl;
+    unsigned long long *counter; // [1] statistics (diagnostic kernel)
     int *err_flag;               // traversal stack overflow (cannot happen for depth <= 64)
 };
 
+// Closed-interval overlap on the 4 dimensions (src/sim_broad_phase.cpp:149-151). Written with
+// wave-wide ballots: every comparison is one v_cmp into an SGPR pair and the conjunction is
+// scalar s_and_b64 work (per-lane boolean algebra costs the compiler ~3 VALU ops per term).
+CSC_DEV unsigned long long bp_overlap_mask(const float4 &plb, const float4 &pub, const float4 &nl, const float4 &nu)
+{
+    unsigned long long m = __ballot(pub.x >= nl.x);
+    m &= __ballot(plb.x <= nu.x);
+    m &= __ballot(pub.y >= nl.y);
+    m &= __ballot(plb.y <= nu.y);
+    m &= __ballot(pub.z >= nl.z);
+    m &= __ballot(plb.z <= nu.z);
+    m &= __ballot(pub.w >= nl.w);
+    m &= __ballot(plb.w <= nu.w);
+    return m;
+}
 CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, const float4 &nu)
 {
     return (pub.x >= nl.x && plb.x <= nu.x) && (pub.y >= nl.y && plb.y <= nu.y) && (pub.z >= nl.z && plb.z <= nu.z)
@@ -454,7 +509,7 @@ CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, 
 }
 
 constexpr int BPG_STACK = 768; // pending internal nodes of one wave
-constexpr int BPG_PAIRQ = 256; // staged pairs of one wave
+constexpr int BPG_PAIRQ = PB_SIZE + 64; // staged pairs of one wave: one pair block + one emission
 
 // tn is passed on its own (not inside bp_params) so that it can carry __restrict__: with the
 // node index made wave-uniform (v_readlane) the compiler then fetches the 96-byte record with
@@ -487,53 +542,77 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int sp = 0, npq = 0;
 
+    // Staging buffer -> a freshly allocated pair block, chained in front of this group's list.
+    std::int32_t head_local = -1;
+    std::uint32_t nblk_local = 0;
+    const std::uint32_t shard = (blockIdx.y * gridDim.x + blockIdx.x) % PL_SHARDS;
+    // Moves the first min(npq, PB_SIZE) staged pairs into a new block (mid-walk flushes are
+    // always full blocks, so that the narrow phase's waves are full) and keeps the rest.
     auto flush = [&]() {
         __syncthreads();
-        unsigned long long base = 0;
+        const int nout = npq < PB_SIZE ? npq : PB_SIZE;
+        unsigned long long old = 0;
         if (lane == 0) {
-            base = atomicAdd(q.counter, static_cast<unsigned long long>(npq));
+            old = atomicAdd(q.pl.shard_ctr + shard * PL_CTR_STRIDE, (1ull << 40) | static_cast<unsigned long long>(nout));
         }
-        base = __shfl(base, 0);
-        for (int k = lane; k < npq; k += 64) {
-            const unsigned long long slot = base + static_cast<unsigned long long>(k);
-            if (slot < q.cap) {
-                const uint2 pr = pairq[k];
-                q.pairs[slot] = make_uint4(pr.x, pr.y, c, 0u);
+        const unsigned long long local = __shfl(old, 0) >> 40;
+        if (local < q.pl.cap_per_shard) {
+            const std::uint32_t blk = shard * q.pl.cap_per_shard + static_cast<std::uint32_t>(local);
+            if (lane == 0) {
+                q.pl.pb_count[blk] = static_cast<std::uint32_t>(nout);
+                q.pl.pb_next[blk] = head_local;
+            }
+            head_local = static_cast<std::int32_t>(blk);
+            ++nblk_local;
+            uint2 *dst = q.pl.pairs + static_cast<std::size_t>(blk) * PB_SIZE;
+            for (int k = lane; k < nout; k += 64) {
+                dst[k] = pairq[k];
             }
         }
-        npq = 0;
+        const int rem = npq - nout; // < 64
+        uint2 carry = make_uint2(0u, 0u);
+        if (lane < rem) {
+            carry = pairq[nout + lane];
+        }
+        __syncthreads();
+        if (lane < rem) {
+            pairq[lane] = carry;
+        }
+        npq = rem;
         __syncthreads();
     };
-    auto emit = [&](bool e, std::uint32_t oi) {
-        const unsigned long long mask = __ballot(e);
+    const unsigned long long my_bit = 1ull << lane;
+    const unsigned long long act_mask = __ballot(act_p);
+    // mask: the lanes that emit (their query, oi).
+    auto emit = [&](unsigned long long mask, std::uint32_t oi) {
         if (mask != 0ull) {
-            if (e) {
+            if (mask & my_bit) {
                 pairq[npq + __popcll(mask & lt_mask)] = make_uint2(orig_p, oi);
             }
             npq += __popcll(mask);
-            if (npq > BPG_PAIRQ - 64) {
+            if (npq >= PB_SIZE) {
                 flush();
             }
         }
     };
-    // A leaf whose box at least one lane overlaps (hit = this lane's test).
-    auto leaf = [&](bool hit, int tag, int begin, int end, int orig) {
+    // A leaf whose box the lanes of `hit` overlap.
+    auto leaf = [&](unsigned long long hit, int tag, int begin, int end, int orig) {
         if (end - begin == 1) {
             const std::uint32_t oi = static_cast<std::uint32_t>(orig);
-            emit(hit && orig_p < oi && (act_p || tag != -1), oi);
+            emit(hit & __ballot(orig_p < oi) & (tag != -1 ? ~0ull : act_mask), oi);
         } else {
             // Multi-particle leaf (equal Morton codes): the test is against the LEAF box for
             // every member (src/sim_broad_phase.cpp:161-168).
             for (std::uint32_t m = static_cast<std::uint32_t>(begin); m != static_cast<std::uint32_t>(end); ++m) {
                 const std::uint32_t oi = q.vidx[po + m];
-                emit(hit && orig_p < oi && (act_p || q.active[oi] != 0), oi);
+                emit(hit & __ballot(orig_p < oi) & (q.active[oi] != 0 ? ~0ull : act_mask), oi);
             }
         }
     };
 
     {
-        const bool hroot = bp_overlap(plb, pub, q.nlb[no], q.nub[no]);
-        if (__ballot(hroot) == 0ull) {
+        const unsigned long long hroot = bp_overlap_mask(plb, pub, q.nlb[no], q.nub[no]);
+        if (hroot == 0ull) {
             return;
         }
         if (q.nleft[no] < 0) {
@@ -562,9 +641,8 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
             const tnode *t = tn + node; // wave-uniform address
             const float4 lb0 = t->lb0, ub0 = t->ub0, lb1 = t->lb1, ub1 = t->ub1;
             const int4 c0 = t->c0, c1 = t->c1;
-            const bool h0 = bp_overlap(plb, pub, lb0, ub0), h1 = bp_overlap(plb, pub, lb1, ub1);
-            const bool any0 = __ballot(h0) != 0ull, any1 = __ballot(h1) != 0ull;
-            if (any0) {
+            const unsigned long long h0 = bp_overlap_mask(plb, pub, lb0, ub0), h1 = bp_overlap_mask(plb, pub, lb1, ub1);
+            if (h0 != 0ull) {
                 if (c0.x >= 0) {
                     if (lane == 0) {
                         stack[sp] = c0.x;
@@ -574,7 +652,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
                     leaf(h0, c0.x, c0.y, c0.z, c0.w);
                 }
             }
-            if (any1) {
+            if (h1 != 0ull) {
                 if (c1.x >= 0) {
                     if (lane == 0) {
                         stack[sp] = c1.x;
@@ -596,6 +674,11 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     }
     if (npq > 0) {
         flush();
+    }
+    if (lane == 0) {
+        q.pl.head[lin] = head_local;
+        q.pl.nblk[lin] = nblk_local;
+        q.pl.tchunk[lin] = c;
     }
 }
 

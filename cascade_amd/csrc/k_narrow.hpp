@@ -23,6 +23,7 @@
 #pragma once
 
 #include "dev_math.hpp"
+#include "k_bvh.hpp"
 #include "k_propagate.hpp"
 
 namespace csc
@@ -54,8 +55,10 @@ struct np_params {
     const double *tcs_xyz;        // CSR rows of tc_xyz_stride(P)
     const double *tcs_vr;         // CSR rows of tc_vr_stride(P)
     const double *tcoords;        // CSR rows of 2
-    const uint4 *pairs;           // [npairs] {i, j, chunk, 0}
-    std::uint64_t npairs;
+    const uint2 *order;           // [norder] {pair block, time chunk}, group-major (k_pl_order)
+    std::uint32_t norder;
+    const std::uint32_t *pb_count; // pairs in each block
+    const uint2 *pairs;           // [block][PB_SIZE] {i, j}
     coll_rec *coll;
     conj_rec *conj;
     std::uint32_t coll_cap, conj_cap;
@@ -402,54 +405,60 @@ CSC_DEV double np_rsum2(const np_params &q, std::uint32_t pi, std::uint32_t pj)
 template <int P>
 __global__ __launch_bounds__(64) void k_np_fex(const np_params q)
 {
-    // Consecutive pairs share Taylor rows (the list is grouped by 64 Morton-consecutive queries).
-    const std::uint64_t k = static_cast<std::uint64_t>(xcd_remap(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
-    if (k >= q.npairs) {
-        return;
-    }
-    const uint4 rec = q.pairs[k];
-    const std::uint32_t pi = rec.x, pj = rec.y, c = rec.z;
+    // Four waves per pair block, pair blocks in group-major order: neighbouring workgroups share
+    // Taylor rows (same 64 queries, largely the same partners), so they are dealt to the XCDs in
+    // runs.
+    const std::uint32_t wg = xcd_remap<64>(blockIdx.x, gridDim.x);
+    const uint2 ent = q.order[wg / (PB_SIZE / 64)];
+    const std::uint32_t blk = ent.x, c = ent.y, t = (wg % (PB_SIZE / 64)) * 64u + threadIdx.x;
     if (c >= q.nchunks) {
         // Chunk dropped by a terminal-event shrink of the superstep (src/sim_narrow_phase.cpp:560).
         return;
     }
-    const std::uint8_t ai = q.active[pi], aj = q.active[pj];
-    const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
-    const double rsum2 = coll_act ? np_rsum2(q, pi, pj) : 0.;
     const dfl chunk_begin = np_chunk_begin(q, c), chunk_end = np_chunk_end(q, c);
-
-    const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
-    const std::uint32_t ns_i = q.nsub[pi], ns_j = q.nsub[pj];
-    std::uint32_t it_i, end_i, it_j, end_j;
-    substep_range(q.tcoords, off_i, ns_i, chunk_begin, chunk_end, it_i, end_i);
-    substep_range(q.tcoords, off_j, ns_j, chunk_begin, chunk_end, it_j, end_j);
-
-    while (it_i != end_i && it_j != end_j) {
-        const np_window w = np_make_window(q, chunk_begin, chunk_end, off_i, it_i, off_j, it_j);
-        if (!w.ok) {
-            atomicOr(&q.counters[2], 16u);
-            break;
+    {
+        if (t >= q.pb_count[blk]) {
+            return;
         }
-        if (w.delta_i != 0. || w.delta_j != 0.) {
-            const std::uint32_t slot = atomicAdd(&q.counters[4], 1u);
-            if (slot < q.defer_cap) {
-                q.defer[2u * slot] = make_uint4(pi, pj, c, 0u);
-                q.defer[2u * slot + 1u] = make_uint4(it_i, it_j, 0u, 0u);
-            }
-        } else {
-            double ss[P + 1];
-            np_build_ss<P, false>(ss, q.tcs_xyz, off_i + it_i, off_j + it_j, 0., 0.);
-            if (!np_check_window<P>(q, ss, coll_act, conj_act, rsum2, w.rf_int, pi, pj, c, it_i, it_j)) {
+        const uint2 rec = q.pairs[static_cast<std::size_t>(blk) * PB_SIZE + t];
+        const std::uint32_t pi = rec.x, pj = rec.y;
+        const std::uint8_t ai = q.active[pi], aj = q.active[pj];
+        const bool coll_act = ((ai | aj) & 1u) != 0, conj_act = ((ai | aj) & 2u) != 0;
+        const double rsum2 = coll_act ? np_rsum2(q, pi, pj) : 0.;
+
+        const std::uint64_t off_i = q.tc_row[pi], off_j = q.tc_row[pj];
+        const std::uint32_t ns_i = q.nsub[pi], ns_j = q.nsub[pj];
+        std::uint32_t it_i, end_i, it_j, end_j;
+        substep_range(q.tcoords, off_i, ns_i, chunk_begin, chunk_end, it_i, end_i);
+        substep_range(q.tcoords, off_j, ns_j, chunk_begin, chunk_end, it_j, end_j);
+
+        while (it_i != end_i && it_j != end_j) {
+            const np_window w = np_make_window(q, chunk_begin, chunk_end, off_i, it_i, off_j, it_j);
+            if (!w.ok) {
+                atomicOr(&q.counters[2], 16u);
                 break;
             }
-        }
-        if (df_lt(w.tend_i, w.tend_j)) {
-            ++it_i;
-        } else if (df_lt(w.tend_j, w.tend_i)) {
-            ++it_j;
-        } else {
-            ++it_i;
-            ++it_j;
+            if (w.delta_i != 0. || w.delta_j != 0.) {
+                const std::uint32_t slot = atomicAdd(&q.counters[4], 1u);
+                if (slot < q.defer_cap) {
+                    q.defer[2u * slot] = make_uint4(pi, pj, c, 0u);
+                    q.defer[2u * slot + 1u] = make_uint4(it_i, it_j, 0u, 0u);
+                }
+            } else {
+                double ss[P + 1];
+                np_build_ss<P, false>(ss, q.tcs_xyz, off_i + it_i, off_j + it_j, 0., 0.);
+                if (!np_check_window<P>(q, ss, coll_act, conj_act, rsum2, w.rf_int, pi, pj, c, it_i, it_j)) {
+                    break;
+                }
+            }
+            if (df_lt(w.tend_i, w.tend_j)) {
+                ++it_i;
+            } else if (df_lt(w.tend_j, w.tend_i)) {
+                ++it_j;
+            } else {
+                ++it_i;
+                ++it_j;
+            }
         }
     }
 }

@@ -202,10 +202,11 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
 /* ---- K6: broad phase -------------------------------------------------------------------
  * broad_phase_parallel (src/sim_broad_phase.cpp:44-218) on the trees of the last
  * csc_bvh_build. d_active [n] u8: bit 0 coll_active, bit 1 conj_active
- * (src/sim_propagate.cpp:639-647). The pair list lives in the context: one {i, j, chunk, 0}
- * u32x4 record per pair (i < j), all chunks in one list, in no particular order (the
- * reference's per-chunk vectors are unordered too, tbb::concurrent_vector). Synchronises
- * (the total is read back); *n_pairs = total over chunks. */
+ * (src/sim_propagate.cpp:639-647). The pairs live in the context as blocks of up to 256 {i, j}
+ * u32 pairs (i < j), every block holding pairs of one group of 64 Morton-consecutive query
+ * particles of one chunk, listed group by group for the narrow phase; within that the order
+ * is unspecified (the reference's per-chunk vectors are unordered too, tbb::concurrent_vector).
+ * Synchronises (the totals are read back); *n_pairs = total over chunks. */
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs);
 /* Diagnostic (measurement only): re-runs the traversal of the last csc_broad_phase without
