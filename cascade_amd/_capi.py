@@ -91,7 +91,7 @@ SYMBOLS = {
     "csc_profile_enable": (_i32, [_vp, _i32]),
     "csc_profile_reset": (_i32, [_vp]),
     "csc_profile_get": (_i32, [_vp, C.c_char_p, _sz]),
-    "csc_propagate": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 9),
+    "csc_propagate": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 10),
     "csc_propagate_summary": (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(PropSummary)]),
     "csc_exclusive_scan": (_i32, [_vp, _vp, _u64, _vp]),
     "csc_tc_strides": (_i32, [_u32, C.POINTER(_u32), C.POINTER(_u32)]),
@@ -99,13 +99,14 @@ SYMBOLS = {
     "csc_global_aabb": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "csc_morton_encode": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "csc_check_flags": (_i32, [_vp]),
-    "csc_sort_gather": (_i32, [_vp, _u32, _u32] + [_vp] * 7),
+    "csc_sort_gather": (_i32, [_vp, _u32, _u32] + [_vp] * 9),
     "csc_bvh_build": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "csc_bvh_export": (_i32, [_vp, _u32, _vp, _u64, C.POINTER(_u64)]),
     "csc_broad_phase": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "csc_broad_phase_stats": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "csc_broad_phase_get": (_i32, [_vp, _u32, _vp, _u64, C.POINTER(_u64)]),
-    "csc_narrow_phase": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 7 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
+    "csc_narrow_phase": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 8 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
+    "csc_narrow_phase_candidates": (_u64, [_vp]),
     "csc_narrow_phase_pairs": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 9 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
     "csc_narrow_phase_get": (_i32, [_vp, _vp, _u64, _vp, _u64]),
     "csc_dense_propagate": (_i32, [_vp, _u32, _u32, _dbl] + [_vp] * 6),

@@ -54,11 +54,13 @@ struct csc_ctx {
     uint32_t bp_blocks = 0, bp_cap_per_shard = 0; // pair blocks used / pool capacity
     csc::pair_lists bp_pl{};
     const uint2 *bp_order = nullptr; // group-major {block, time chunk} list of the last broad phase
+    const uint32_t *bp_vidx = nullptr; // the permutation the pair positions refer to
     uint32_t bp_n = 0, bp_chunks = 0;
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
     std::vector<csc_conjunction> conj;
+    uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
     // per-kernel HIP-event timing (csc_profile_*)
     struct ktimer {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
@@ -290,15 +292,19 @@ __global__ __launch_bounds__(256) void k_gather_u32(uint32_t n, const uint32_t *
     }
 }
 
-// Caller-provided [npairs][2] pairs -> pair blocks: block b takes count[b] pairs from src_start[b].
-__global__ __launch_bounds__(256) void k_pack_pairs(const uint32_t *pairs, const uint64_t *src_start, const uint32_t *count,
-                                                    uint2 *out)
+// Caller-provided [npairs][2] pairs with per-chunk offsets -> {i, j, chunk, 0} candidates.
+__global__ __launch_bounds__(256) void k_tag_pairs(uint64_t npairs, const uint32_t *pairs, const uint64_t *off,
+                                                   uint32_t nchunks, uint4 *out)
 {
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
-    if (t < count[b]) {
-        const uint64_t k = src_start[b] + t;
-        out[static_cast<size_t>(b) * csc::PB_SIZE + t] = make_uint2(pairs[k * 2u], pairs[k * 2u + 1u]);
+    const uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= npairs) {
+        return;
     }
+    uint32_t c = 0;
+    while (c + 1u < nchunks && off[c + 1u] <= k) {
+        ++c;
+    }
+    out[k] = make_uint4(pairs[k * 2u], pairs[k * 2u + 1u], c, 0u);
 }
 
 csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const double *d_state)
@@ -536,7 +542,7 @@ int csc_check_flags(csc_ctx *ctx)
 
 int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                   int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
-                  double *d_final_state, float *d_lbs, float *d_ubs)
+                  double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs)
 {
     if (const int rc = check_cfg(ctx, cfg)) {
         return rc;
@@ -553,6 +559,7 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
     p.final_state = d_final_state;
     p.lbs = d_lbs;
     p.ubs = d_ubs;
+    p.recs = d_recs;
     const bool events = cfg->has_exit || cfg->has_reentry;
     const dim3 grid(cdiv(n, 64)), block(64);
     if (events) {
@@ -722,8 +729,11 @@ static int radix_sort(csc_ctx *ctx, uint32_t n, uint32_t nseg, int nbits, uint64
 
 int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_codes, const float *d_lbs,
                     const float *d_ubs, uint32_t *d_vidx, uint64_t *d_srt_codes, float *d_srt_lbs,
-                    float *d_srt_ubs)
+                    float *d_srt_ubs, const float *d_recs, float *d_srt_recs)
 {
+    if ((d_recs == nullptr) != (d_srt_recs == nullptr)) {
+        return ctx->invalid("d_recs and d_srt_recs must be given together");
+    }
     const size_t tot = static_cast<size_t>(n) * nchunks;
     CSC_BUF(d_ka, uint64_t, "sort_keys_a", tot);
     CSC_BUF(d_va, uint32_t, "sort_vals_a", tot);
@@ -741,7 +751,8 @@ int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *
     CSC_HIP(hipMemcpyAsync(d_vidx, vres, tot * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     KT("k_gather_aabb", hipLaunchKernelGGL(csc::k_gather_aabb, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), d_vidx, n,
-                       reinterpret_cast<float4 *>(d_srt_lbs), reinterpret_cast<float4 *>(d_srt_ubs)));
+                       reinterpret_cast<float4 *>(d_srt_lbs), reinterpret_cast<float4 *>(d_srt_ubs),
+                       reinterpret_cast<const float4 *>(d_recs), reinterpret_cast<float4 *>(d_srt_recs)));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -942,6 +953,7 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     ctx->bp_blocks = static_cast<uint32_t>(total_blocks);
     ctx->bp_pl = q.pl;
     ctx->bp_order = d_order;
+    ctx->bp_vidx = d_vidx;
     ctx->bp_n = n;
     ctx->bp_chunks = nchunks;
     *n_pairs = total_pairs;
@@ -989,6 +1001,9 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
         CSC_HIP(hipMemcpyAsync(order.data(), ctx->bp_order, nb * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
     }
     CSC_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> vx(ctx->bp_n);
+    CSC_HIP(hipMemcpy(vx.data(), ctx->bp_vidx + static_cast<size_t>(chunk) * ctx->bp_n, vx.size() * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
     uint64_t k = 0;
     std::vector<uint2> h(csc::PB_SIZE);
     for (uint32_t e = 0; e < nb; ++e) {
@@ -1001,8 +1016,8 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
                           hipMemcpyDeviceToHost));
         for (uint32_t t = 0; t < cnt; ++t, ++k) {
             if (k < cap) {
-                pairs[k * 2u] = h[t].x;
-                pairs[k * 2u + 1u] = h[t].y;
+                pairs[k * 2u] = vx[h[t].x];
+                pairs[k * 2u + 1u] = vx[h[t].y];
             }
         }
     }
@@ -1012,11 +1027,24 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
 
 // ---- K7 --------------------------------------------------------------------------------
 
+// Where the narrow phase takes its candidate pairs from.
+struct np_source {
+    // (a) the pair blocks of the last broad phase (sorted positions), optionally pre-filtered
+    const uint2 *order = nullptr;
+    uint32_t norder = 0;
+    const uint32_t *pb_count = nullptr;
+    const uint2 *pb_pairs = nullptr;
+    const uint32_t *vidx = nullptr;
+    const float *srt_recs = nullptr; // null: no pre-filter, every pair is a candidate
+    // (b) a ready-made candidate list {pi, pj, chunk, 0} (original indices)
+    const uint4 *cand = nullptr;
+    uint64_t npairs = 0; // number of pairs of the source (capacity bound for the candidates)
+};
+
 static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                        double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
                        const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
-                       const double *d_tcs_vr, const double *d_tcoords, const uint2 *d_order, uint32_t norder,
-                       const uint32_t *d_pb_count, const uint2 *d_pb_pairs, uint64_t npairs, uint64_t *n_coll,
+                       const double *d_tcs_vr, const double *d_tcoords, const np_source &src, uint64_t *n_coll,
                        uint64_t *n_conj, uint32_t *warn_flags)
 {
     if (order != 20u) {
@@ -1025,25 +1053,42 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
     }
     ctx->coll.clear();
     ctx->conj.clear();
+    ctx->np_candidates = 0;
     *n_coll = 0;
     *n_conj = 0;
     if (warn_flags) {
         *warn_flags = 0;
     }
-    if (npairs == 0) {
+    if (src.npairs == 0) {
         return CSC_OK;
+    }
+    if (src.npairs > 0xffffff00ull && src.cand == nullptr && src.srt_recs == nullptr) {
+        return ctx->invalid("too many pairs for an unfiltered narrow phase");
     }
     CSC_BUF(d_cnt, uint32_t, "np_counters", 8);
     uint32_t coll_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_coll"].cap / sizeof(csc::coll_rec), 4096));
     uint32_t conj_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_conj"].cap / sizeof(csc::conj_rec), 4096));
     uint32_t surv_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_surv"].cap / (2 * sizeof(uint4)), 65536));
     uint32_t defer_cap = static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_defer"].cap / (2 * sizeof(uint4)), 65536));
+    // Candidates: everything when there is no pre-filter, else what the last superstep needed.
+    uint32_t cand_cap;
+    if (src.cand != nullptr || src.srt_recs == nullptr) {
+        cand_cap = static_cast<uint32_t>(src.npairs);
+    } else {
+        cand_cap = static_cast<uint32_t>(std::min<uint64_t>(
+            src.npairs, std::max<size_t>(ctx->bufs["np_cand"].cap / sizeof(uint4), 262144)));
+    }
     uint32_t h[8];
     for (int attempt = 0; attempt < 4; ++attempt) {
         CSC_BUF(d_coll, csc::coll_rec, "np_coll", coll_cap);
         CSC_BUF(d_conj, csc::conj_rec, "np_conj", conj_cap);
         CSC_BUF(d_surv, uint4, "np_surv", static_cast<size_t>(surv_cap) * 2u);
         CSC_BUF(d_defer, uint4, "np_defer", static_cast<size_t>(defer_cap) * 2u);
+        uint4 *d_cand = nullptr;
+        if (src.cand == nullptr) {
+            CSC_BUF(d_cand_, uint4, "np_cand", cand_cap);
+            d_cand = d_cand_;
+        }
         CSC_HIP(hipMemsetAsync(d_cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
         csc::np_params q{};
         q.n = n;
@@ -1053,6 +1098,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.init_hi = init_time_hi;
         q.init_lo = init_time_lo;
         q.conj_thresh2 = conj_thresh * conj_thresh;
+        q.thr_extra = conj_thresh;
         q.state = d_state;
         q.active = d_active;
         q.tc_row = d_tc_row;
@@ -1060,10 +1106,14 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.tcs_xyz = d_tcs_xyz;
         q.tcs_vr = d_tcs_vr;
         q.tcoords = d_tcoords;
-        q.order = d_order;
-        q.norder = norder;
-        q.pb_count = d_pb_count;
-        q.pairs = d_pb_pairs;
+        q.order = src.order;
+        q.norder = src.norder;
+        q.pb_count = src.pb_count;
+        q.pairs = src.pb_pairs;
+        q.vidx = src.vidx;
+        q.srt_recs = reinterpret_cast<const float4 *>(src.srt_recs);
+        q.cand = src.cand ? const_cast<uint4 *>(src.cand) : d_cand;
+        q.cand_cap = cand_cap;
         q.coll = d_coll;
         q.conj = d_conj;
         q.coll_cap = coll_cap;
@@ -1073,17 +1123,28 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.defer = d_defer;
         q.defer_cap = defer_cap;
         q.counters = d_cnt;
-        // Fast exclusion over all pairs (windows that need a polynomial translation in a second
-        // kernel), then root finding over the survivors. The grids of the follow-up kernels cover
-        // the list capacities; lanes beyond the device-side counts exit at once.
-        KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(norder * (csc::PB_SIZE / 64)), dim3(64), 0, ctx->stream, q));
+        // Pre-filter over all pairs -> candidates; fast exclusion over the candidates (windows
+        // that need a polynomial translation in a second kernel); root finding over the
+        // survivors. The grids of the follow-up kernels cover the list capacities; lanes beyond
+        // the device-side counts exit at once.
+        if (src.cand != nullptr) {
+            const uint32_t nc = static_cast<uint32_t>(src.npairs);
+            CSC_HIP(hipMemcpyAsync(d_cnt + 5, &nc, sizeof(nc), hipMemcpyHostToDevice, ctx->stream));
+        } else if (src.srt_recs != nullptr) {
+            KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter<true>), dim3(src.norder * (csc::PB_SIZE / 64)), dim3(64), 0,
+                                                     ctx->stream, q));
+        } else {
+            KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter<false>), dim3(src.norder * (csc::PB_SIZE / 64)), dim3(64), 0,
+                                                     ctx->stream, q));
+        }
+        KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(cdiv(cand_cap, 64)), dim3(64), 0, ctx->stream, q));
         KT("k_np_fex_tr", hipLaunchKernelGGL((csc::k_np_fex_tr<20>), dim3(cdiv(defer_cap, 64)), dim3(64), 0, ctx->stream, q));
-        const unsigned rg = cdiv(surv_cap, 64);
-        KT("k_np_roots", hipLaunchKernelGGL((csc::k_np_roots<20>), dim3(rg), dim3(64), 0, ctx->stream, q));
+        KT("k_np_roots", hipLaunchKernelGGL((csc::k_np_roots<20>), dim3(cdiv(surv_cap, 64)), dim3(64), 0, ctx->stream, q));
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
-        if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap) {
+        if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap && h[5] <= cand_cap) {
+            ctx->np_candidates = h[5];
             ctx->coll.resize(h[0]);
             ctx->conj.resize(h[1]);
             if (h[0]) {
@@ -1114,6 +1175,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         conj_cap = std::max(conj_cap, h[1] + h[1] / 4u + 16u);
         surv_cap = std::max(surv_cap, h[3] + h[3] / 4u + 16u);
         defer_cap = std::max(defer_cap, h[4] + h[4] / 4u + 16u);
+        cand_cap = std::max(cand_cap, h[5] + h[5] / 4u + 16u);
     }
     ctx->err = "narrow phase output overflow";
     return CSC_ERR_OVERFLOW;
@@ -1122,17 +1184,23 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
 int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                      double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
                      const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
-                     const double *d_tcs_vr, const double *d_tcoords, uint64_t *n_coll, uint64_t *n_conj,
-                     uint32_t *warn_flags)
+                     const double *d_tcs_vr, const double *d_tcoords, const float *d_srt_recs, uint64_t *n_coll,
+                     uint64_t *n_conj, uint32_t *warn_flags)
 {
     if (n != ctx->bp_n || nchunks > ctx->bp_chunks) {
         return ctx->invalid("narrow phase does not match the last broad phase");
     }
-    // After a terminal-event shrink the kernel skips the pairs of the dropped chunks.
+    // After a terminal-event shrink the kernels skip the pairs of the dropped chunks.
+    np_source src;
+    src.order = ctx->bp_order;
+    src.norder = ctx->bp_blocks;
+    src.pb_count = ctx->bp_pl.pb_count;
+    src.pb_pairs = ctx->bp_pl.pairs;
+    src.vidx = ctx->bp_vidx;
+    src.srt_recs = d_srt_recs;
+    src.npairs = ctx->bp_total;
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
-                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords,
-                       ctx->bp_order, ctx->bp_blocks, ctx->bp_pl.pb_count, ctx->bp_pl.pairs, ctx->bp_total, n_coll, n_conj,
-                       warn_flags);
+                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, src, n_coll, n_conj, warn_flags);
 }
 
 int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
@@ -1142,34 +1210,29 @@ int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct
                            const uint32_t *d_pairs, const uint64_t *pair_off, uint64_t *n_coll, uint64_t *n_conj,
                            uint32_t *warn_flags)
 {
-    // One pair block per 256 injected pairs of a chunk.
     const uint64_t npairs = pair_off[nchunks];
-    std::vector<uint64_t> src_start;
-    std::vector<uint32_t> count;
-    std::vector<uint2> blk_order;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        for (uint64_t k = pair_off[c]; k < pair_off[c + 1u]; k += csc::PB_SIZE) {
-            blk_order.push_back(make_uint2(static_cast<uint32_t>(count.size()), c));
-            src_start.push_back(k);
-            count.push_back(static_cast<uint32_t>(std::min<uint64_t>(csc::PB_SIZE, pair_off[c + 1u] - k)));
-        }
+    if (npairs > 0xffffff00ull) {
+        return ctx->invalid("too many injected pairs");
     }
-    const uint32_t nb = static_cast<uint32_t>(count.size());
-    CSC_BUF(d_src, uint64_t, "np_inj_src", std::max(nb, 1u));
-    CSC_BUF(d_cnt, uint32_t, "np_inj_count", std::max(nb, 1u));
-    CSC_BUF(d_ord, uint2, "np_inj_order", std::max(nb, 1u));
-    CSC_BUF(d_rec, uint2, "np_inj_pairs", static_cast<size_t>(std::max(nb, 1u)) * csc::PB_SIZE);
-    if (nb) {
-        CSC_HIP(hipMemcpyAsync(d_src, src_start.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        CSC_HIP(hipMemcpyAsync(d_cnt, count.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        CSC_HIP(hipMemcpyAsync(d_ord, blk_order.data(), nb * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-        KT("k_pack_pairs", hipLaunchKernelGGL(k_pack_pairs, dim3(nb), dim3(csc::PB_SIZE), 0, ctx->stream, d_pairs, d_src, d_cnt, d_rec));
+    CSC_BUF(d_off, uint64_t, "np_pair_off", nchunks + 1u);
+    CSC_BUF(d_rec, uint4, "np_pair_rec", std::max<uint64_t>(npairs, 1));
+    CSC_HIP(hipMemcpyAsync(d_off, pair_off, (nchunks + 1u) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    if (npairs) {
+        KT("k_tag_pairs", hipLaunchKernelGGL(k_tag_pairs, dim3(cdiv(npairs, 256)), dim3(256), 0, ctx->stream, npairs, d_pairs, d_off,
+                                              nchunks, d_rec));
         CSC_LAUNCH_CHECK();
-        CSC_HIP(hipStreamSynchronize(ctx->stream)); // the host vectors go out of scope
     }
+    np_source src;
+    src.cand = d_rec;
+    src.npairs = npairs;
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
-                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, d_ord, nb, d_cnt, d_rec, npairs, n_coll, n_conj,
-                       warn_flags);
+                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, src, n_coll, n_conj, warn_flags);
+}
+
+uint64_t csc_narrow_phase_candidates(csc_ctx *ctx)
+{
+    return ctx->np_candidates;
 }
 
 int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,

@@ -444,7 +444,7 @@ constexpr int PL_SHARDS = 32;
 constexpr int PL_CTR_STRIDE = 16; // counters are 128 bytes apart
 
 struct pair_lists {
-    uint2 *pairs;            // [cap_blocks][PB_SIZE] {i, j}, i < j
+    uint2 *pairs;            // [cap_blocks][PB_SIZE] {pos_i, pos_j}: sorted positions, vidx[pos_i] < vidx[pos_j]
     std::uint32_t *pb_count; // [cap_blocks] pairs in the block
     std::int32_t *pb_next;   // [cap_blocks] next block of the same list, -1 = end
     std::int32_t *head;      // [nlists] first block of the list (valid when nblk > 0)
@@ -583,11 +583,12 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     };
     const unsigned long long my_bit = 1ull << lane;
     const unsigned long long act_mask = __ballot(act_p);
-    // mask: the lanes that emit (their query, oi).
-    auto emit = [&](unsigned long long mask, std::uint32_t oi) {
+    // mask: the lanes that emit the pair (their query, particle at sorted position pos). Pairs
+    // are recorded as SORTED POSITIONS within the chunk (vidx maps them to original indices).
+    auto emit = [&](unsigned long long mask, std::uint32_t pos) {
         if (mask != 0ull) {
             if (mask & my_bit) {
-                pairq[npq + __popcll(mask & lt_mask)] = make_uint2(orig_p, oi);
+                pairq[npq + __popcll(mask & lt_mask)] = make_uint2(pidx, pos);
             }
             npq += __popcll(mask);
             if (npq >= PB_SIZE) {
@@ -599,13 +600,13 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     auto leaf = [&](unsigned long long hit, int tag, int begin, int end, int orig) {
         if (end - begin == 1) {
             const std::uint32_t oi = static_cast<std::uint32_t>(orig);
-            emit(hit & __ballot(orig_p < oi) & (tag != -1 ? ~0ull : act_mask), oi);
+            emit(hit & __ballot(orig_p < oi) & (tag != -1 ? ~0ull : act_mask), static_cast<std::uint32_t>(begin));
         } else {
             // Multi-particle leaf (equal Morton codes): the test is against the LEAF box for
             // every member (src/sim_broad_phase.cpp:161-168).
             for (std::uint32_t m = static_cast<std::uint32_t>(begin); m != static_cast<std::uint32_t>(end); ++m) {
                 const std::uint32_t oi = q.vidx[po + m];
-                emit(hit & __ballot(orig_p < oi) & (q.active[oi] != 0 ? ~0ull : act_mask), oi);
+                emit(hit & __ballot(orig_p < oi) & (q.active[oi] != 0 ? ~0ull : act_mask), m);
             }
         }
     };

@@ -168,8 +168,10 @@ __global__ __launch_bounds__(256) void k_morton(const float4 *lbs, const float4 
 }
 
 // grid (ceil(n / 256), C).
+// recs / srt_recs: the 64-byte sampled-trajectory records (may be null).
 __global__ __launch_bounds__(256) void k_gather_aabb(const float4 *lbs, const float4 *ubs, const std::uint32_t *vidx,
-                                                     std::uint32_t n, float4 *srt_lbs, float4 *srt_ubs)
+                                                     std::uint32_t n, float4 *srt_lbs, float4 *srt_ubs,
+                                                     const float4 *recs, float4 *srt_recs)
 {
     const std::uint32_t chunk = blockIdx.y;
     const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,6 +182,12 @@ __global__ __launch_bounds__(256) void k_gather_aabb(const float4 *lbs, const fl
     const std::uint32_t s = vidx[off + i];
     srt_lbs[off + i] = lbs[off + s];
     srt_ubs[off + i] = ubs[off + s];
+    if (recs != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            srt_recs[(off + i) * 4u + k] = recs[(off + s) * 4u + k];
+        }
+    }
 }
 
 } // namespace csc

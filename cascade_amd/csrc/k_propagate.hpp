@@ -70,6 +70,7 @@ struct prop_params {
     double *nf_last_t;
     double *final_state; // [N][6]
     float *lbs, *ubs;    // [C][N][4]
+    float *recs;         // [C][N][16] sampled-trajectory records for the narrow-phase pre-filter (may be null)
     // pass 2
     const std::uint32_t *order;     // [N] particle handled by lane k (null = identity)
     const std::uint64_t *row_base;  // [N] first CSR row of lane k
@@ -273,6 +274,21 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
     const float finf = __builtin_huge_valf();
     const double infl = dmax(p_radius, prm.conj_thresh / 2);
 
+    // Sampled-trajectory record of the chunk being visited (see np_prefilter in k_narrow.hpp):
+    // positions at the 5 times cb + s (ce - cb) / 4, and a bound on |p''| over the chunk.
+    float smp[15];
+    std::uint32_t smask = 0;
+    double sbound = 0., sabs = 0.;
+    const bool want_recs = !STORE && prm.recs != nullptr;
+    if constexpr (!STORE) {
+        if (want_recs) {
+            // Chunks that are never completed keep an invalid record (dev = +inf: never excluded).
+            for (std::uint32_t k = 0; k < C; ++k) {
+                float4 *pr = reinterpret_cast<float4 *>(prm.recs) + (static_cast<std::size_t>(k) * prm.n + i) * 4u;
+                pr[3] = make_float4(0.f, 0.f, 0.f, finf);
+            }
+        }
+    }
     if constexpr (!STORE) {
         // Boxes of chunks that no substep reaches stay at +-inf (:238-244).
         for (std::uint32_t k = 0; k < C; ++k) {
@@ -289,6 +305,21 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
                 float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(kbox) * prm.n + i);
                 *plo = make_float4(blo[0], blo[1], blo[2], blo[3]);
                 *phi = make_float4(bhi[0], bhi[1], bhi[2], bhi[3]);
+                if (want_recs) {
+                    const double cb = prm.ct * static_cast<double>(kbox);
+                    const double ce = (kbox == C - 1u) ? prm.delta_t : prm.ct * static_cast<double>(kbox + 1u);
+                    const double dts = (ce - cb) * 0.25;
+                    // |p(t) - chord(t)| <= dt^2 / 8 * max |p''| on each quarter of the chunk, plus the
+                    // particle's radius, plus a margin for the single-precision storage and
+                    // arithmetic of the filter.
+                    double dev = sbound * dts * dts * 0.125 + p_radius + 1e-6 * sabs;
+                    float devf = (smask == 0x1fu && finite_d(dev)) ? nextafterf(static_cast<float>(dev), finf) : finf;
+                    float4 *pr = reinterpret_cast<float4 *>(prm.recs) + (static_cast<std::size_t>(kbox) * prm.n + i) * 4u;
+                    pr[0] = make_float4(smp[0], smp[1], smp[2], smp[3]);
+                    pr[1] = make_float4(smp[4], smp[5], smp[6], smp[7]);
+                    pr[2] = make_float4(smp[8], smp[9], smp[10], smp[11]);
+                    pr[3] = make_float4(smp[12], smp[13], smp[14], devf);
+                }
             }
         }
     };
@@ -442,6 +473,41 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
                         for (int q = 0; q < 4; ++q) {
                             blo[q] = finf;
                             bhi[q] = -finf;
+                        }
+                        smask = 0;
+                        sbound = 0.;
+                        sabs = 0.;
+                    }
+                    if (want_recs) {
+                        const double hs = df_sub(tc, tc_prev).hi;
+                        // Bound on |p''| over this substep: sum k (k - 1) |c_k| h^(k - 2), per coordinate.
+                        double b2 = 0.;
+                        {
+                            const double *arrs3[3] = {t.x, t.y, t.z};
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) {
+                                double acc = 0.;
+#pragma unroll
+                                for (int o = P; o >= 2; --o) {
+                                    acc = fma(acc, hs, static_cast<double>(o * (o - 1)) * fabs(arrs3[q][o]));
+                                }
+                                b2 = fma(acc, acc, b2);
+                            }
+                        }
+                        sbound = dmax(sbound, sqrt(b2));
+                        const double dts = (ce - cb) * 0.25;
+#pragma unroll
+                        for (int sidx = 0; sidx < 5; ++sidx) {
+                            const dfl ts = df(sidx == 4 ? ce : cb + dts * static_cast<double>(sidx));
+                            if (!df_lt(ts, tc_prev) && !df_lt(tc, ts)) {
+                                const double tau = df_sub(ts, tc_prev).hi;
+                                const double sx = horner_fma<P>(t.x, tau), sy = horner_fma<P>(t.y, tau), sz = horner_fma<P>(t.z, tau);
+                                smp[3 * sidx] = static_cast<float>(sx);
+                                smp[3 * sidx + 1] = static_cast<float>(sy);
+                                smp[3 * sidx + 2] = static_cast<float>(sz);
+                                smask |= 1u << sidx;
+                                sabs = dmax(sabs, dmax(fabs(sx), dmax(fabs(sy), fabs(sz))));
+                            }
                         }
                     }
                     const double *arrs[4] = {t.x, t.y, t.z, t.r};

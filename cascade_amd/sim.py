@@ -160,6 +160,7 @@ class sim:
         self.stage_ms = {}
         self.last_bp_pairs = 0
         self.host_sync = True
+        self.np_prefilter = True  # geometric pre-filter in front of the polynomial narrow phase
 
     # ---- validation helpers ---------------------------------------------------------
     def _validate_pars(self, pars, nparts):
@@ -437,6 +438,9 @@ class sim:
         d_slbs = self._buf("srt_lbs", (nchunks0, n, 4), f32)
         d_subs = self._buf("srt_ubs", (nchunks0, n, 4), f32)
         d_tc_row = self._buf("tc_row", (n,), u64)
+        # Sampled-trajectory records for the narrow phase's geometric pre-filter.
+        d_recs = self._buf("recs", (nchunks0, n, 16), f32) if self.np_prefilter else None
+        d_srecs = self._buf("srt_recs", (nchunks0, n, 16), f32) if self.np_prefilter else None
 
         ms = {}
 
@@ -454,7 +458,7 @@ class sim:
         chk(L.csc_activity_flags(h, n, d_state, self._min_coll_radius, 1 if with_conj else 0, cw.ctypes.data_as(C.c_void_p), len(cw), jw.ctypes.data_as(C.c_void_p), len(jw), d_active))
 
         cfg = self._cfg(nchunks0, delta_t0)
-        chk(L.csc_propagate(h, C.byref(cfg), n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs))
+        chk(L.csc_propagate(h, C.byref(cfg), n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs))
         summ = _capi.PropSummary()
         chk(L.csc_propagate_summary(h, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, C.byref(summ)))
         lap("propagate")
@@ -486,7 +490,7 @@ class sim:
 
         chk(L.csc_global_aabb(h, n, nchunks, d_lbs, d_ubs, d_glb, d_gub))
         chk(L.csc_morton_encode(h, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes))
-        chk(L.csc_sort_gather(h, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs))
+        chk(L.csc_sort_gather(h, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs))
         lap("morton_sort")
 
         # Taylor coefficients for dense output: CSR rows in the Morton order of chunk 0, so
@@ -512,13 +516,14 @@ class sim:
         ncoll, nconj, warn = C.c_uint64(), C.c_uint64(), C.c_uint32()
         chk(
             L.csc_narrow_phase(
-                h, n, nchunks, self._ct, delta_t, self._time.hi, self._time.lo, self._conj_thresh, self._order, d_state, d_active, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, C.byref(ncoll), C.byref(nconj), C.byref(warn)
+                h, n, nchunks, self._ct, delta_t, self._time.hi, self._time.lo, self._conj_thresh, self._order, d_state, d_active, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, C.byref(ncoll), C.byref(nconj), C.byref(warn)
             )
         )
         coll = np.empty(int(ncoll.value), dtype=_capi.COLL_DTYPE)
         conj = np.empty(int(nconj.value), dtype=_capi.CONJ_DTYPE)
         chk(L.csc_narrow_phase_get(h, coll.ctypes.data_as(C.c_void_p), len(coll), conj.ctypes.data_as(C.c_void_p), len(conj)))
         self.last_collisions = coll
+        self.last_np_candidates = int(L.csc_narrow_phase_candidates(h))
         self.last_step_conjunctions = conj
         lap("narrow")
 

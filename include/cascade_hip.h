@@ -141,10 +141,13 @@ int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap);
  * propagate_for (EXTERNAL). d_state [n][7] f64. Outputs: d_nsub [n] u32 (substeps taken),
  * d_status [n] i32, d_ev_idx [n] u32, d_ev_time [n] f64 (terminal event time relative to
  * the superstep start), d_nf_last_t [n] f64, d_final_state [n][6] f64,
- * d_lbs / d_ubs [nchunks][n][4] f32. Asynchronous. */
+ * d_lbs / d_ubs [nchunks][n][4] f32. d_recs (may be NULL) [nchunks][n][16] f32: per particle and
+ * chunk, the positions at the 5 times cb + s (ce - cb) / 4 (15 floats) and a radius that bounds
+ * the distance of the trajectory from the chords through them plus the particle's size; input
+ * of the narrow phase's geometric pre-filter (no counterpart in the reference). Asynchronous. */
 int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                   int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
-                  double *d_final_state, float *d_lbs, float *d_ubs);
+                  double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs);
 
 /* Reductions over the per-particle records (earliest nf state / terminal event, flags,
  * total substeps): src/sim_propagate.cpp:1127-1153. Synchronises; fills *out on the host. */
@@ -185,10 +188,11 @@ int csc_check_flags(csc_ctx *ctx); /* synchronises; returns and clears the pendi
 
 /* Stable indirect sort by code (src/sim_propagate.cpp:483-486; STABLE where oneTBB's
  * parallel_sort leaves ties unspecified) and gather (:493-504). d_vidx [nchunks][n] u32,
- * d_srt_codes [nchunks][n] u64, d_srt_lbs / d_srt_ubs [nchunks][n][4] f32. Asynchronous. */
+ * d_srt_codes [nchunks][n] u64, d_srt_lbs / d_srt_ubs [nchunks][n][4] f32. d_recs / d_srt_recs
+ * (both NULL or both given): the records of csc_propagate, gathered the same way. Asynchronous. */
 int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_codes, const float *d_lbs,
                     const float *d_ubs, uint32_t *d_vidx, uint64_t *d_srt_codes, float *d_srt_lbs,
-                    float *d_srt_ubs);
+                    float *d_srt_ubs, const float *d_recs, float *d_srt_recs);
 
 /* ---- K5: BVH ---------------------------------------------------------------------------
  * construct_bvh_trees_parallel (src/sim_bvh.cpp:89-496). The trees live in the context.
@@ -222,12 +226,18 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
 /* ---- K7: narrow phase ------------------------------------------------------------------
  * narrow_phase_parallel (src/sim_narrow_phase.cpp:495-1023) over the pair list of the last
  * csc_broad_phase. nchunks / delta_t are the values AFTER a possible terminal-event shrink
- * (:560). Results live in the context; synchronises; counts returned. */
+ * (:560). d_srt_recs: the sorted records of csc_sort_gather; when given, a rigorous geometric
+ * pre-filter (chord distance of the sampled trajectories, see k_np_prefilter) discards the
+ * pairs that cannot come within max(r_i + r_j, conj_thresh) of each other before the
+ * reference's polynomial test; NULL runs that test on every pair (same events either way).
+ * Results live in the context; synchronises; counts returned. csc_narrow_phase_candidates:
+ * number of pairs that reached the polynomial test in the last call. */
 int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                      double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
                      const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
-                     const double *d_tcs_vr, const double *d_tcoords, uint64_t *n_coll, uint64_t *n_conj,
-                     uint32_t *warn_flags);
+                     const double *d_tcs_vr, const double *d_tcoords, const float *d_srt_recs, uint64_t *n_coll,
+                     uint64_t *n_conj, uint32_t *warn_flags);
+uint64_t csc_narrow_phase_candidates(csc_ctx *ctx);
 /* Same, on a caller-provided pair list d_pairs [npairs][2] with per-chunk row offsets
  * pair_off [nchunks + 1] (host array). For parity checks on injected pairs. */
 int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,

@@ -76,7 +76,7 @@ def test_aabb_to_pairs_bit_exact(orc, ctx, n, n_par_ct, same_code):
     codes = d_codes.download()
     d_vidx, d_sc = ctx.empty((C_, n), np.uint32), ctx.empty((C_, n), np.uint64)
     d_slb, d_sub = ctx.empty((C_, n, 4), np.float32), ctx.empty((C_, n, 4), np.float32)
-    chk(L.csc_sort_gather(h, n, C_, d_codes.ptr, d_lbs.ptr, d_ubs.ptr, d_vidx.ptr, d_sc.ptr, d_slb.ptr, d_sub.ptr))
+    chk(L.csc_sort_gather(h, n, C_, d_codes.ptr, d_lbs.ptr, d_ubs.ptr, d_vidx.ptr, d_sc.ptr, d_slb.ptr, d_sub.ptr, None, None))
     vidx, sc, slb, sub = d_vidx.download(), d_sc.download(), d_slb.download(), d_sub.download()
     chk(L.csc_bvh_build(h, n, C_, d_sc.ptr, d_slb.ptr, d_sub.ptr))
     ca, cj = s.active_flags()
@@ -153,7 +153,7 @@ def _gpu_propagate(ctx, st, cfg_kw, order=None):
         lbs=ctx.empty((Cn, n, 4), np.float32),
         ubs=ctx.empty((Cn, n, 4), np.float32),
     )
-    chk(L.csc_propagate(h, C.byref(cfg), n, d_state.ptr, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, d["final"].ptr, d["lbs"].ptr, d["ubs"].ptr))
+    chk(L.csc_propagate(h, C.byref(cfg), n, d_state.ptr, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, d["final"].ptr, d["lbs"].ptr, d["ubs"].ptr, None))
     summ = _capi.PropSummary()
     chk(L.csc_propagate_summary(h, n, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, C.byref(summ)))
     tot = int(summ.total_substeps)

@@ -211,3 +211,33 @@ def test_steps_vs_oracle(orc, n, n_par_ct, conj, scale):
         assert np.all(np.abs(cg["dist"] - co["dist"]) <= 1e-9)
     if scale > 1:
         assert n_int > 0, "the scaled population should produce collisions"
+
+
+@pytest.mark.parametrize("n,n_par_ct,conj,scale", [(20000, 1, 0.0, 1.0), (8000, 1, 2e-3, 3e3), (6000, 4, 1e-3, 3e4), (4000, 2, 0.0, 1e5)])
+def test_prefilter_changes_nothing(n, n_par_ct, conj, scale):
+    """The geometric pre-filter of the narrow phase (k_np_prefilter, no counterpart in the
+    reference) must not change a single event: same collisions and conjunctions, bit for bit,
+    with and without it, while most AABB pairs never reach the polynomial test."""
+    from cascade_amd import sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(n, seed=11)
+    st[:, 6] *= scale
+    a = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
+    b = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
+    b.np_prefilter = False
+    n_events = 0
+    for _ in range(4):
+        oa, ob = a.step(), b.step()
+        assert oa == ob and a.interrupt_info == b.interrupt_info
+        assert a.last_bp_pairs == b.last_bp_pairs
+        assert b.last_np_candidates == b.last_bp_pairs
+        assert a.last_np_candidates <= a.last_bp_pairs
+        assert a.last_collisions.tobytes() == b.last_collisions.tobytes()
+        assert a.last_step_conjunctions.tobytes() == b.last_step_conjunctions.tobytes()
+        assert np.array_equal(a.state, b.state)
+        n_events += len(a.last_collisions) + len(a.last_step_conjunctions)
+        if a.last_bp_pairs > 1000:
+            assert a.last_np_candidates < 0.5 * a.last_bp_pairs, (a.last_np_candidates, a.last_bp_pairs)
+    if scale > 1 or conj > 0:
+        assert n_events > 0, "the test population should produce events"
