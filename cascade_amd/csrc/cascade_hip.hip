@@ -900,6 +900,10 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     CSC_BUF(d_tchunk, uint32_t, "bp_tchunk", nlists);
     CSC_BUF(d_off, uint32_t, "bp_list_off", nlists + 1u);
     CSC_BUF(d_ctr, unsigned long long, "bp_shard_ctr", csc::PL_SHARDS * csc::PL_CTR_STRIDE);
+#ifdef CSC_BP_GROUP_STATS
+    CSC_BUF(d_gstats, uint32_t, "bp_gstats", 2 * static_cast<size_t>(nlists));
+    q.gstats = d_gstats;
+#endif
     // Pair blocks come from per-shard pools; the pool capacity follows the last superstep's use
     // (populations change slowly), and an overflow re-runs the traversal.
     uint32_t cap_ps = std::max<uint32_t>({ctx->bp_cap_per_shard, cdiv(nlists * 2u, csc::PL_SHARDS), 64u});
@@ -959,6 +963,14 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     *n_pairs = total_pairs;
     return CSC_OK;
 }
+
+#ifdef CSC_BP_GROUP_STATS
+int csc_debug_gstats(csc_ctx *ctx, uint32_t *out, uint32_t nlists)
+{
+    CSC_HIP(hipMemcpy(out, ctx->bufs["bp_gstats"].p, 2 * static_cast<size_t>(nlists) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CSC_OK;
+}
+#endif
 
 int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                           const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *nodes_visited)

@@ -485,6 +485,7 @@ struct bp_params {
     pair_lists pl;
     unsigned long long *counter; // [1] statistics (diagnostic kernel)
     int *err_flag;               // traversal stack overflow (cannot happen for depth <= 64)
+    std::uint32_t *gstats;       // debug builds: per group {nodes visited, cycles}
 };
 
 // Closed-interval overlap on the 4 dimensions (src/sim_broad_phase.cpp:149-151). Written with
@@ -541,6 +542,10 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int sp = 0, npq = 0;
+#ifdef CSC_BP_GROUP_STATS
+    std::uint32_t dbg_nodes = 0;
+    const long long dbg_t0 = clock64();
+#endif
 
     // Staging buffer -> a freshly allocated pair block, chained in front of this group's list.
     std::int32_t head_local = -1;
@@ -636,6 +641,9 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
         const int np = (sp > BPG_STACK - 192) ? 1 : (sp < 64 ? sp : 64);
         const std::int32_t my_node = (lane < np) ? stack[sp - 1 - lane] : 0;
         sp -= np;
+#ifdef CSC_BP_GROUP_STATS
+        dbg_nodes += np;
+#endif
         __syncthreads();
         for (int k = 0; k < np; ++k) {
             const std::int32_t node = __builtin_amdgcn_readlane(my_node, k);
@@ -680,6 +688,10 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
         q.pl.head[lin] = head_local;
         q.pl.nblk[lin] = nblk_local;
         q.pl.tchunk[lin] = c;
+#ifdef CSC_BP_GROUP_STATS
+        q.gstats[2 * lin] = dbg_nodes;
+        q.gstats[2 * lin + 1] = static_cast<std::uint32_t>(clock64() - dbg_t0);
+#endif
     }
 }
 
