@@ -169,10 +169,19 @@ class Context:
             raise CascadeHipError(rc, self.L.csc_last_error(None).decode())
         self.h = h.value
 
+    @classmethod
+    def from_handle(cls, handle):
+        """Non-owning wrapper of an existing csc_ctx * (e.g. ``sim._hip_context``)."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.h = int(handle)
+        self._borrowed = True
+        return self
+
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
             self.L.csc_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.close()

@@ -1,0 +1,253 @@
+// cascade_amd/csrc/host/core.cpp
+//
+// Python bindings of cascade::sim (include/cascade/sim.hpp): module cascade_amd.core, the
+// counterpart of the reference's cascade.core (cascade.py/core.cpp:49-359). Same class name,
+// constructor keywords, properties, methods, outcome enum, conjunction dtype, zero-copy
+// writable views of state / pars kept alive by shared_ptr capsules (:199-230), read-only
+// conjunctions (:300-321), GIL released around construction, step() and propagate_until().
+// `dyn` takes the descriptor returned by kepler() instead of heyoka expressions.
+//
+//   g++ -O2 -std=c++17 -fPIC -shared $(python3-config --includes) -I<pybind11> -Iinclude \
+//       core.cpp -Lcascade_amd -lcascade -lcascade_hip -Wl,-rpath,'$ORIGIN' -o cascade_amd/core<ext>.so
+
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <string>
+#include <variant>
+#include <vector>
+
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cascade/sim.hpp>
+
+namespace py = pybind11;
+using namespace cascade;
+using namespace pybind11::literals;
+
+namespace
+{
+
+struct coll_rec {
+    std::uint64_t i, j;
+    double time;
+};
+
+// A numpy view of a vector owned by a shared_ptr: the capsule keeps a copy of the pointer, so
+// the array stays valid after the simulation replaces or drops the vector.
+template <typename T>
+py::array view_of(const std::shared_ptr<std::vector<T>> &sp, std::vector<py::ssize_t> shape, bool writable)
+{
+    auto *keep = new std::shared_ptr<std::vector<T>>(sp);
+    py::capsule base(keep, [](void *p) { delete static_cast<std::shared_ptr<std::vector<T>> *>(p); });
+    py::array ret(py::dtype::of<T>(), std::move(shape), sp->data(), base);
+    if (!writable) {
+        ret.attr("flags").attr("writeable") = false;
+    }
+    return ret;
+}
+
+std::vector<double> flatten2d(const py::array_t<double> &a)
+{
+    return py::cast<std::vector<double>>(a.attr("flatten")());
+}
+
+void check_state_array(const py::array_t<double> &state)
+{
+    if (state.ndim() != 2) {
+        throw std::invalid_argument("The input state must have 2 dimensions, but instead an array with "
+                                    + std::to_string(state.ndim()) + " dimension(s) was provided");
+    }
+    if (state.shape(1) != 7) {
+        throw std::invalid_argument("An input state with 7 columns is expected, but the number of columns is instead "
+                                    + std::to_string(state.shape(1)));
+    }
+}
+
+std::vector<double> pars_vector(const std::optional<py::array_t<double>> &pars_, py::ssize_t nparts)
+{
+    std::vector<double> pars_vec;
+    if (pars_) {
+        const auto &pars = *pars_;
+        if (pars.ndim() != 2) {
+            throw std::invalid_argument("The input array of parameter values must have 2 dimensions, but "
+                                        "instead an array with "
+                                        + std::to_string(pars.ndim()) + " dimension(s) was provided");
+        }
+        if (pars.shape(0) != nparts) {
+            throw std::invalid_argument("An input array of parameter values with " + std::to_string(nparts)
+                                        + " row(s) is expected, but the number of rows is instead "
+                                        + std::to_string(pars.shape(0)));
+        }
+        pars_vec = flatten2d(pars);
+    }
+    return pars_vec;
+}
+
+} // namespace
+
+PYBIND11_MODULE(core, m)
+{
+    m.doc() = "MI355X-native cascade.core";
+
+    py::class_<dynamics::dyn_t>(m, "dyn_t")
+        .def_readonly("mu", &dynamics::dyn_t::mu)
+        .def_readonly("npars", &dynamics::dyn_t::npars)
+        .def_property_readonly("kind", [](const dynamics::dyn_t &d) { return static_cast<int>(d.kind); })
+        .def("__repr__", [](const dynamics::dyn_t &d) {
+            std::ostringstream oss;
+            oss << "kepler(mu=" << d.mu << ")";
+            return oss.str();
+        });
+    m.def("_kepler", &dynamics::kepler, "mu"_a = 1.);
+
+    py::enum_<outcome>(m, "outcome")
+        .value("success", outcome::success)
+        .value("time_limit", outcome::time_limit)
+        .value("collision", outcome::collision)
+        .value("reentry", outcome::reentry)
+        .value("exit", outcome::exit)
+        .value("err_nf_state", outcome::err_nf_state);
+
+    PYBIND11_NUMPY_DTYPE(sim::conjunction, i, j, time, dist, state_i, state_j);
+    PYBIND11_NUMPY_DTYPE(coll_rec, i, j, time);
+
+    using whitelist_t = sim::whitelist_t;
+    py::class_<sim>(m, "sim", py::dynamic_attr{})
+        .def(py::init<>())
+        .def(py::init([](const py::array_t<double> &state, double ct, std::optional<dynamics::dyn_t> dyn_,
+                         std::optional<std::variant<double, std::vector<double>>> reentry_radius_,
+                         std::optional<double> exit_radius_, const std::optional<py::array_t<double>> &pars_,
+                         std::optional<double> tol_, bool ha, bool cm, std::uint32_t n_par_ct, double conj_thresh,
+                         double min_coll_radius, whitelist_t coll_whitelist, whitelist_t conj_whitelist, int device) {
+                 check_state_array(state);
+                 sim::options o;
+                 o.dyn = dyn_ ? *dyn_ : dynamics::kepler();
+                 o.reentry_radius = reentry_radius_ ? std::move(*reentry_radius_) : std::variant<double, std::vector<double>>{0.};
+                 o.exit_radius = exit_radius_ ? *exit_radius_ : 0.;
+                 o.pars = pars_vector(pars_, state.shape(0));
+                 o.tol = tol_ ? *tol_ : 0.;
+                 o.high_accuracy = ha;
+                 o.compact_mode = cm;
+                 o.n_par_ct = n_par_ct;
+                 o.conj_thresh = conj_thresh;
+                 o.min_coll_radius = min_coll_radius;
+                 o.coll_whitelist = std::move(coll_whitelist);
+                 o.conj_whitelist = std::move(conj_whitelist);
+                 o.device = device;
+                 auto state_vec = flatten2d(state);
+                 py::gil_scoped_release release;
+                 return sim(std::move(state_vec), ct, std::move(o));
+             }),
+             "state"_a, "ct"_a, "dyn"_a = py::none{}, "reentry_radius"_a = py::none{}, "exit_radius"_a = py::none{},
+             "pars"_a = py::none{}, "tol"_a = py::none{}, "high_accuracy"_a = false, "compact_mode"_a = false,
+             "n_par_ct"_a = 1, "conj_thresh"_a = 0., "min_coll_radius"_a = 0., "coll_whitelist"_a = whitelist_t{},
+             "conj_whitelist"_a = whitelist_t{}, "device"_a = 0)
+        .def_property_readonly("interrupt_info", &sim::get_interrupt_info)
+        .def_property("time", &sim::get_time, &sim::set_time)
+        .def_property("ct", &sim::get_ct, &sim::set_ct)
+        .def_property("n_par_ct", &sim::get_n_par_ct, &sim::set_n_par_ct)
+        .def_property("conj_thresh", &sim::get_conj_thresh, &sim::set_conj_thresh)
+        .def_property("min_coll_radius", &sim::get_min_coll_radius, &sim::set_min_coll_radius)
+        .def_property("coll_whitelist", &sim::get_coll_whitelist, &sim::set_coll_whitelist)
+        .def_property("conj_whitelist", &sim::get_conj_whitelist, &sim::set_conj_whitelist)
+        .def_property_readonly("nparts", &sim::get_nparts)
+        .def_property_readonly("npars", &sim::get_npars)
+        .def_property_readonly("tol", &sim::get_tol)
+        .def_property_readonly("high_accuracy", &sim::get_high_accuracy)
+        .def_property_readonly("compact_mode", &sim::get_compact_mode)
+        .def_property_readonly("reentry_radius", &sim::get_reentry_radius)
+        .def_property_readonly("exit_radius", &sim::get_exit_radius)
+        .def(
+            "step",
+            [](sim &s) {
+                py::gil_scoped_release release;
+                return s.step();
+            })
+        .def(
+            "propagate_until",
+            [](sim &s, double t) {
+                py::gil_scoped_release release;
+                return s.propagate_until(t);
+            },
+            "t"_a)
+        .def_property_readonly("state",
+                               [](const sim &s) {
+                                   auto sp = s._get_state_ptr();
+                                   const auto n = static_cast<py::ssize_t>(sp->size() / 7u);
+                                   return view_of(sp, {n, 7}, true);
+                               })
+        .def_property_readonly("pars",
+                               [](const sim &s) {
+                                   auto sp = s._get_pars_ptr();
+                                   const auto np = static_cast<py::ssize_t>(s.get_npars());
+                                   const auto n = static_cast<py::ssize_t>(s.get_nparts());
+                                   return view_of(sp, {n, np}, true);
+                               })
+        .def_property_readonly("conjunctions",
+                               [](const sim &s) {
+                                   auto sp = s._get_conjunctions_ptr();
+                                   return view_of(sp, {static_cast<py::ssize_t>(sp->size())}, false);
+                               })
+        .def("reset_conjunctions", &sim::reset_conjunctions)
+        .def(
+            "set_new_state_pars",
+            [](sim &s, const py::array_t<double> &new_state, const std::optional<py::array_t<double>> &new_pars) {
+                check_state_array(new_state);
+                auto pv = pars_vector(new_pars, new_state.shape(0));
+                auto sv = flatten2d(new_state);
+                py::gil_scoped_release release;
+                s.set_new_state_pars(std::move(sv), std::move(pv));
+            },
+            "new_state"_a, "new_pars"_a = py::none{})
+        .def("remove_particles", &sim::remove_particles, "idxs"_a)
+        .def("__repr__",
+             [](const sim &s) {
+                 std::ostringstream oss;
+                 oss << s;
+                 return oss.str();
+             })
+        // ---- additions of this build (measurement and residency control) ---------------
+        .def_property_readonly("dyn", &sim::get_dyn)
+        .def_property_readonly("device", &sim::get_device)
+        .def_property("host_sync", &sim::get_host_sync, &sim::set_host_sync)
+        .def_property("np_prefilter", &sim::get_np_prefilter, &sim::set_np_prefilter)
+        .def("bp_nodes_visited", &sim::bp_nodes_visited)
+        .def("upload_state", &sim::upload_state)
+        .def("download_state", &sim::download_state)
+        .def_property_readonly("last_bp_pairs", [](const sim &s) { return s.get_step_stats().bp_pairs; })
+        .def_property_readonly("last_np_candidates", [](const sim &s) { return s.get_step_stats().np_candidates; })
+        .def_property_readonly("last_total_substeps", [](const sim &s) { return s.get_step_stats().total_substeps; })
+        .def_property_readonly("last_nchunks", [](const sim &s) { return s.get_step_stats().nchunks; })
+        .def_property_readonly("last_collisions",
+                               [](const sim &s) {
+                                   const auto &v = s.get_last_collisions();
+                                   py::array_t<coll_rec> out(static_cast<py::ssize_t>(v.size()));
+                                   auto *p = static_cast<coll_rec *>(out.mutable_data());
+                                   for (std::size_t k = 0; k < v.size(); ++k) {
+                                       p[k] = coll_rec{std::get<0>(v[k]), std::get<1>(v[k]), std::get<2>(v[k])};
+                                   }
+                                   return out;
+                               })
+        .def_property_readonly("last_step_conjunctions",
+                               [](const sim &s) {
+                                   const auto &v = s.get_last_step_conjunctions();
+                                   py::array_t<sim::conjunction> out(static_cast<py::ssize_t>(v.size()));
+                                   std::copy(v.begin(), v.end(), static_cast<sim::conjunction *>(out.mutable_data()));
+                                   return out;
+                               })
+        .def_property_readonly("_hip_context", [](sim &s) { return reinterpret_cast<std::uintptr_t>(s._get_hip_context()); });
+
+    // Thread-count control of the reference (cascade.py/core.cpp:332-348): the pipeline runs on
+    // the GPU, so these only record the value.
+    static unsigned nthreads = 0;
+    m.def("set_nthreads", [](unsigned n) { nthreads = n; }, "n"_a);
+    m.def("get_nthreads", []() { return nthreads; });
+    // Logger levels of the reference (cascade.py/logging.cpp:19-29): accepted, no logger here.
+    for (const char *lvl : {"trace", "debug", "info", "warn", "err", "critical"}) {
+        m.def((std::string("set_logger_level_") + lvl).c_str(), []() {});
+    }
+}

@@ -1,0 +1,917 @@
+// cascade_amd/csrc/host/sim.cpp
+//
+// Host side of cascade::sim (include/cascade/sim.hpp): argument validation, state ownership,
+// outcome logic, conjunction bookkeeping, propagate_until -- the parts of the reference's
+// src/sim_basic.cpp and src/sim_propagate.cpp that stay on the CPU -- and the orchestration of
+// the per-superstep pipeline through the C ABI of libcascade_hip.so (include/cascade_hip.h).
+// Plain C++17 compiled with g++: nothing here touches HIP directly.
+//
+//   g++ -O2 -std=c++17 -fPIC -shared -Iinclude cascade_amd/csrc/host/sim.cpp \
+//       -Lcascade_amd -lcascade_hip -Wl,-rpath,'$ORIGIN' -o cascade_amd/libcascade.so
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <ostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+#include <cascade/sim.hpp>
+#include <cascade_hip.h>
+
+namespace cascade
+{
+
+namespace dynamics
+{
+
+dyn_t kepler(double mu)
+{
+    dyn_t d;
+    d.kind = dyn_t::kepler;
+    d.mu = mu;
+    d.npars = 0;
+    return d;
+}
+
+} // namespace dynamics
+
+namespace
+{
+
+// Shortest round-trip text of a double, like fmt's "{}" (the reference formats its messages
+// with fmt: "... but it is -1 instead", "... [1, 2, 0]").
+std::string fmt_d(double x)
+{
+    if (std::isnan(x)) {
+        return "nan";
+    }
+    if (std::isinf(x)) {
+        return x < 0 ? "-inf" : "inf";
+    }
+    char buf[64];
+    const auto r = std::to_chars(buf, buf + sizeof(buf), x);
+    return std::string(buf, r.ptr);
+}
+
+template <typename V>
+std::string fmt_list(const V &v)
+{
+    std::string s = "[";
+    bool first = true;
+    for (const auto &x : v) {
+        if (!first) {
+            s += ", ";
+        }
+        first = false;
+        if constexpr (std::is_floating_point_v<std::decay_t<decltype(x)>>) {
+            s += fmt_d(x);
+        } else {
+            s += std::to_string(x);
+        }
+    }
+    return s + "]";
+}
+
+// heyoka::detail::dfloat<double> (EXTERNAL): normalised hi + lo.
+struct dfloat {
+    double hi = 0, lo = 0;
+};
+
+dfloat df_add(dfloat x, dfloat y)
+{
+    const double s = x.hi + y.hi;
+    const double z = s - x.hi;
+    double e = (x.hi - (s - z)) + (y.hi - z);
+    e += x.lo + y.lo;
+    const double h = s + e;
+    return dfloat{h, e - (h - s)};
+}
+
+dfloat df_sub(dfloat x, dfloat y)
+{
+    return df_add(x, dfloat{-y.hi, -y.lo});
+}
+
+bool df_lt(dfloat a, dfloat b)
+{
+    return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
+}
+
+bool df_eq(dfloat a, dfloat b)
+{
+    return a.hi == b.hi && a.lo == b.lo;
+}
+
+std::uint32_t order_from_tol(double tol)
+{
+    // heyoka's order rule (EXTERNAL): max(2, ceil(-ln(tol) / 2 + 1)).
+    const double o = std::ceil(-std::log(tol) / 2 + 1);
+    return o < 2 ? 2u : static_cast<std::uint32_t>(o);
+}
+
+} // namespace
+
+// Per-step scratch (the role of sim::sim_data, include/cascade/detail/sim_data.hpp:90-318):
+// here the device context and the grow-only device buffers.
+struct sim::sim_data {
+    dynamics::dyn_t dyn;
+    double tol = 0;
+    bool high_accuracy = false, compact_mode = false;
+    std::uint32_t order = 0;
+    int device = 0;
+    dfloat time;
+    bool host_sync = true, np_prefilter = true;
+    step_stats stats;
+    std::vector<std::tuple<size_type, size_type, double>> last_coll;
+    std::vector<conjunction> last_conj;
+
+    csc_ctx *ctx = nullptr;
+    struct dbuf {
+        void *p = nullptr;
+        std::size_t bytes = 0;
+    };
+    std::map<std::string, dbuf> bufs;
+
+    sim_data() = default;
+    // A copy shares nothing on the device: it gets its own context on its first step().
+    sim_data(const sim_data &o)
+        : dyn(o.dyn), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
+          device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter)
+    {
+    }
+    ~sim_data()
+    {
+        release();
+    }
+    void release()
+    {
+        if (ctx) {
+            for (auto &kv : bufs) {
+                if (kv.second.p) {
+                    csc_free(ctx, kv.second.p);
+                }
+            }
+            bufs.clear();
+            csc_ctx_destroy(ctx);
+            ctx = nullptr;
+        }
+    }
+    void ensure_ctx()
+    {
+        if (!ctx) {
+            const int rc = csc_ctx_create(device, &ctx);
+            if (rc != CSC_OK) {
+                ctx = nullptr;
+                throw std::runtime_error(std::string("cascade: cannot create the HIP context (there is no CPU fallback): ")
+                                         + csc_last_error(nullptr));
+            }
+        }
+    }
+    void chk(int rc) const
+    {
+        if (rc != CSC_OK) {
+            const std::string msg = csc_last_error(ctx);
+            switch (rc) {
+                case CSC_ERR_INVALID:
+                case CSC_ERR_NONFINITE_AABB:
+                case CSC_ERR_NONFINITE_TIME:
+                case CSC_ERR_NO_SUBSTEPS:
+                    throw std::invalid_argument(msg);
+                case CSC_ERR_MAX_SUBSTEPS:
+                case CSC_ERR_OVERFLOW:
+                    throw std::overflow_error(msg);
+                default:
+                    throw std::runtime_error("libcascade_hip error " + std::to_string(rc) + ": " + msg);
+            }
+        }
+    }
+    // Grow-only named device buffer (like resize_if_needed, src/sim_propagate.cpp:561-569).
+    template <typename T>
+    T *buf(const char *name, std::size_t count)
+    {
+        auto &b = bufs[name];
+        const std::size_t bytes = std::max<std::size_t>(count * sizeof(T), 256);
+        if (b.bytes < bytes) {
+            if (b.p) {
+                chk(csc_free(ctx, b.p));
+                b.p = nullptr;
+                b.bytes = 0;
+            }
+            const std::size_t want = bytes + bytes / 4;
+            chk(csc_malloc(ctx, want, &b.p));
+            b.bytes = want;
+        }
+        return static_cast<T *>(b.p);
+    }
+    template <typename T>
+    T *get(const char *name)
+    {
+        return static_cast<T *>(bufs[name].p);
+    }
+};
+
+sim::sim(ptag_t, std::vector<double> state, double ct)
+    : m_state(std::make_shared<std::vector<double>>(std::move(state))), m_pars(std::make_shared<std::vector<double>>()),
+      m_ct(ct), m_det_conj(std::make_shared<std::vector<conjunction>>()), m_data(std::make_unique<sim_data>())
+{
+}
+
+sim::sim() : sim(std::vector<double>{}, 1.) {}
+
+sim::sim(const sim &o)
+    : m_state(std::make_shared<std::vector<double>>(*o.m_state)), m_pars(std::make_shared<std::vector<double>>(*o.m_pars)),
+      m_ct(o.m_ct), m_n_par_ct(o.m_n_par_ct), m_int_info(o.m_int_info), m_reentry_radius(o.m_reentry_radius),
+      m_exit_radius(o.m_exit_radius), m_npars(o.m_npars), m_conj_thresh(o.m_conj_thresh),
+      m_det_conj(std::make_shared<std::vector<conjunction>>(*o.m_det_conj)), m_min_coll_radius(o.m_min_coll_radius),
+      m_coll_whitelist(o.m_coll_whitelist), m_conj_whitelist(o.m_conj_whitelist),
+      m_data(std::make_unique<sim_data>(*o.m_data))
+{
+}
+
+sim::sim(sim &&) noexcept = default;
+
+sim &sim::operator=(const sim &o)
+{
+    if (this != &o) {
+        *this = sim(o);
+    }
+    return *this;
+}
+
+sim &sim::operator=(sim &&) noexcept = default;
+
+sim::~sim() = default;
+
+bool sim::with_reentry_event() const
+{
+    if (const auto *p = std::get_if<double>(&m_reentry_radius)) {
+        return *p > 0;
+    }
+    return true;
+}
+
+bool sim::with_exit_event() const
+{
+    return m_exit_radius > 0;
+}
+
+// src/sim_basic.cpp:359-615 (the heyoka integrator construction is replaced by the dynamics
+// descriptor; everything else -- checks, messages, defaults -- follows the reference).
+void sim::finalise_ctor(options o)
+{
+    if (m_state->size() % 7u != 0u) {
+        throw std::invalid_argument("The size of the state vector is " + std::to_string(m_state->size())
+                                    + ", which is not a multiple of 7");
+    }
+    if (!std::isfinite(m_ct) || m_ct <= 0) {
+        throw std::invalid_argument("The collisional timestep must be finite and positive, but it is " + fmt_d(m_ct)
+                                    + " instead");
+    }
+    set_n_par_ct(o.n_par_ct);
+    set_conj_thresh(o.conj_thresh);
+    set_min_coll_radius(o.min_coll_radius);
+    m_coll_whitelist = std::move(o.coll_whitelist);
+    m_conj_whitelist = std::move(o.conj_whitelist);
+
+    if (o.dyn.kind != dynamics::dyn_t::kepler) {
+        throw std::invalid_argument("Unknown built-in dynamics kind " + std::to_string(static_cast<int>(o.dyn.kind)));
+    }
+    m_data->dyn = o.dyn;
+    m_npars = o.dyn.npars;
+    validate_pars_vector(o.pars, get_nparts());
+    m_pars = std::make_shared<std::vector<double>>(std::move(o.pars));
+
+    // src/sim_basic.cpp:471-501
+    if (const auto *rr = std::get_if<double>(&o.reentry_radius)) {
+        if (!std::isfinite(*rr) || *rr < 0) {
+            throw std::invalid_argument("The reentry radius must be finite and non-negative, but it is " + fmt_d(*rr)
+                                        + " instead");
+        }
+    } else {
+        const auto &v = std::get<std::vector<double>>(o.reentry_radius);
+        if (v.size() != 3u) {
+            throw std::invalid_argument(
+                "The reentry_radius argument must be either a scalar (for a spherical central body) "
+                "or a vector of 3 elements (for a triaxial ellipsoid), but instead it is a vector of "
+                + std::to_string(v.size()) + " element(s)");
+        }
+        if (std::any_of(v.begin(), v.end(), [](double x) { return !std::isfinite(x) || x <= 0; })) {
+            throw std::invalid_argument(
+                "A non-finite or non-positive value was detected among the 3 semiaxes of the central body: "
+                + fmt_list(v));
+        }
+    }
+    m_reentry_radius = std::move(o.reentry_radius);
+    if (!std::isfinite(o.exit_radius) || o.exit_radius < 0) {
+        throw std::invalid_argument("The exit radius must be finite and non-negative, but it is " + fmt_d(o.exit_radius)
+                                    + " instead");
+    }
+    m_exit_radius = o.exit_radius;
+
+    const double tol = o.tol == 0 ? std::numeric_limits<double>::epsilon() : o.tol;
+    if (!std::isfinite(tol) || tol <= 0) {
+        throw std::invalid_argument("The tolerance must be finite and positive, but it is " + fmt_d(tol) + " instead");
+    }
+    m_data->tol = tol;
+    m_data->order = order_from_tol(tol);
+    m_data->high_accuracy = o.high_accuracy;
+    m_data->compact_mode = o.compact_mode;
+    m_data->device = o.device;
+
+    verify_state_vector(*m_state);
+}
+
+// src/sim_basic.cpp:252-278
+void sim::validate_pars_vector(std::vector<double> &pars, size_type nparts) const
+{
+    if (m_npars == 0u) {
+        if (!pars.empty()) {
+            throw std::invalid_argument("The input array of parameter values must be empty when the number of parameters "
+                                        "in the dynamics is zero");
+        }
+    } else if (pars.empty()) {
+        pars.resize(nparts * m_npars);
+    } else if (pars.size() % m_npars != 0u || pars.size() / m_npars != nparts) {
+        throw std::invalid_argument("The input array of parameter values must have shape (" + std::to_string(nparts) + ", "
+                                    + std::to_string(m_npars) + "), but instead its flattened size is "
+                                    + std::to_string(pars.size()));
+    }
+}
+
+// src/sim_basic.cpp:686-760
+void sim::verify_state_vector(const std::vector<double> &st) const
+{
+    if (st.size() % 7u != 0u) {
+        throw std::invalid_argument("The size of the state vector is " + std::to_string(st.size())
+                                    + ", which is not a multiple of 7");
+    }
+    const auto n = st.size() / 7u;
+    const bool reentry = with_reentry_event(), exit_ev = with_exit_event();
+    const auto *ell = std::get_if<std::vector<double>>(&m_reentry_radius);
+    for (size_type i = 0; i < n; ++i) {
+        const double *p = st.data() + i * 7u;
+        const double x = p[0], y = p[1], z = p[2];
+        if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) {
+            throw std::invalid_argument("An non-finite position was detected in the state vector of the particle at index "
+                                        + std::to_string(i));
+        }
+        if (reentry) {
+            if (ell) {
+                const double a = (*ell)[0], b = (*ell)[1], c = (*ell)[2];
+                if (x * x / (a * a) + y * y / (b * b) + z * z / (c * c) < 1) {
+                    throw std::invalid_argument("The particle at index " + std::to_string(i)
+                                                + " is inside the ellipsoidal central body");
+                }
+            } else {
+                const double r = std::get<double>(m_reentry_radius);
+                if (x * x + y * y + z * z < r * r) {
+                    throw std::invalid_argument("The particle at index " + std::to_string(i)
+                                                + " is inside the spherical central body");
+                }
+            }
+        }
+        if (exit_ev && x * x + y * y + z * z >= m_exit_radius * m_exit_radius) {
+            throw std::invalid_argument("The particle at index " + std::to_string(i) + " is outside the exit radius "
+                                        + fmt_d(m_exit_radius));
+        }
+        if (!std::isfinite(p[3]) || !std::isfinite(p[4]) || !std::isfinite(p[5])) {
+            throw std::invalid_argument("An non-finite velocity was detected in the state vector of the particle at index "
+                                        + std::to_string(i));
+        }
+        if (!std::isfinite(p[6]) || p[6] < 0) {
+            throw std::invalid_argument("An invalid particle size of " + fmt_d(p[6])
+                                        + " was detected for the particle at index " + std::to_string(i));
+        }
+    }
+}
+
+// ---- getters / setters -------------------------------------------------------------------
+
+double sim::get_time() const
+{
+    return m_data->time.hi;
+}
+
+void sim::set_time(double t)
+{
+    if (!std::isfinite(t)) {
+        throw std::invalid_argument("Cannot set the simulation time to the non-finite value " + fmt_d(t));
+    }
+    m_data->time = dfloat{t, 0.};
+}
+
+double sim::get_ct() const
+{
+    return m_ct;
+}
+
+void sim::set_ct(double ct)
+{
+    if (!std::isfinite(ct) || ct <= 0) {
+        throw std::invalid_argument("The collisional timestep must be finite and positive, but it is " + fmt_d(ct)
+                                    + " instead");
+    }
+    m_ct = ct;
+}
+
+std::uint32_t sim::get_n_par_ct() const
+{
+    return m_n_par_ct;
+}
+
+void sim::set_n_par_ct(std::uint32_t n)
+{
+    if (n == 0u) {
+        throw std::invalid_argument("The number of collisional timesteps to be processed in parallel cannot be zero");
+    }
+    m_n_par_ct = n;
+}
+
+double sim::get_tol() const
+{
+    return m_data->tol;
+}
+
+bool sim::get_high_accuracy() const
+{
+    return m_data->high_accuracy;
+}
+
+bool sim::get_compact_mode() const
+{
+    return m_data->compact_mode;
+}
+
+std::uint32_t sim::get_npars() const
+{
+    return m_npars;
+}
+
+std::variant<double, std::vector<double>> sim::get_reentry_radius() const
+{
+    return m_reentry_radius;
+}
+
+void sim::set_conj_thresh(double v)
+{
+    if (!std::isfinite(v) || v < 0) {
+        throw std::invalid_argument("The conjunction threshold value " + fmt_d(v)
+                                    + " is invalid: it must be finite and non-negative");
+    }
+    m_conj_thresh = v;
+}
+
+void sim::reset_conjunctions()
+{
+    m_det_conj = std::make_shared<std::vector<conjunction>>();
+}
+
+void sim::set_min_coll_radius(double v)
+{
+    if (std::isnan(v) || v < 0) {
+        throw std::invalid_argument("The minimum collisional radius cannot be NaN or negative, but the invalid value "
+                                    + fmt_d(v) + " was provided");
+    }
+    m_min_coll_radius = v;
+}
+
+void sim::set_coll_whitelist(whitelist_t wl)
+{
+    m_coll_whitelist = std::move(wl);
+}
+
+void sim::set_conj_whitelist(whitelist_t wl)
+{
+    m_conj_whitelist = std::move(wl);
+}
+
+// src/sim_basic.cpp:340-357
+void sim::set_new_state_pars(std::vector<double> new_state, std::vector<double> new_pars)
+{
+    verify_state_vector(new_state);
+    validate_pars_vector(new_pars, new_state.size() / 7u);
+    auto st = std::make_shared<std::vector<double>>(std::move(new_state));
+    auto ps = std::make_shared<std::vector<double>>(std::move(new_pars));
+    m_state = std::move(st);
+    m_pars = std::move(ps);
+}
+
+// src/sim_basic.cpp:280-338
+void sim::remove_particles(std::vector<size_type> idxs)
+{
+    std::sort(idxs.begin(), idxs.end());
+    idxs.erase(std::unique(idxs.begin(), idxs.end()), idxs.end());
+    const auto nparts = get_nparts();
+    if (!idxs.empty() && idxs.back() >= nparts) {
+        throw std::invalid_argument("An invalid vector of indices was passed to the function for particle removal: "
+                                    + fmt_list(idxs));
+    }
+    std::vector<double> new_state, new_pars;
+    new_state.reserve((nparts - idxs.size()) * 7u);
+    new_pars.reserve((nparts - idxs.size()) * m_npars);
+    auto it = idxs.cbegin();
+    for (size_type i = 0; i < nparts; ++i) {
+        if (it != idxs.cend() && *it == i) {
+            ++it;
+            continue;
+        }
+        new_state.insert(new_state.end(), m_state->begin() + i * 7u, m_state->begin() + (i + 1u) * 7u);
+        new_pars.insert(new_pars.end(), m_pars->begin() + i * m_npars, m_pars->begin() + (i + 1u) * m_npars);
+    }
+    auto st = std::make_shared<std::vector<double>>(std::move(new_state));
+    auto ps = std::make_shared<std::vector<double>>(std::move(new_pars));
+    m_state = std::move(st);
+    m_pars = std::move(ps);
+}
+
+const dynamics::dyn_t &sim::get_dyn() const
+{
+    return m_data->dyn;
+}
+
+int sim::get_device() const
+{
+    return m_data->device;
+}
+
+void sim::set_host_sync(bool v)
+{
+    m_data->host_sync = v;
+}
+
+bool sim::get_host_sync() const
+{
+    return m_data->host_sync;
+}
+
+void sim::set_np_prefilter(bool v)
+{
+    m_data->np_prefilter = v;
+}
+
+bool sim::get_np_prefilter() const
+{
+    return m_data->np_prefilter;
+}
+
+const sim::step_stats &sim::get_step_stats() const
+{
+    return m_data->stats;
+}
+
+std::uint64_t sim::bp_nodes_visited()
+{
+    auto &d = *m_data;
+    if (!d.ctx || d.stats.nchunks == 0u) {
+        throw std::invalid_argument("bp_nodes_visited() needs a preceding step()");
+    }
+    std::uint64_t v = 0;
+    d.chk(csc_broad_phase_stats(d.ctx, static_cast<std::uint32_t>(get_nparts()), d.stats.nchunks, d.get<float>("srt_lbs"),
+                                d.get<float>("srt_ubs"), d.get<std::uint32_t>("vidx"), d.get<std::uint8_t>("active"), &v));
+    return v;
+}
+
+const std::vector<std::tuple<sim::size_type, sim::size_type, double>> &sim::get_last_collisions() const
+{
+    return m_data->last_coll;
+}
+
+const std::vector<sim::conjunction> &sim::get_last_step_conjunctions() const
+{
+    return m_data->last_conj;
+}
+
+void *sim::_get_hip_context()
+{
+    m_data->ensure_ctx();
+    return m_data->ctx;
+}
+
+void sim::upload_state()
+{
+    auto &d = *m_data;
+    d.ensure_ctx();
+    const auto n = get_nparts();
+    double *d_state = d.buf<double>("state", n * 7u);
+    if (n) {
+        d.chk(csc_memcpy_h2d(d.ctx, d_state, m_state->data(), n * 7u * sizeof(double)));
+    }
+}
+
+void sim::download_state()
+{
+    auto &d = *m_data;
+    d.ensure_ctx();
+    const auto n = get_nparts();
+    double *d_state = d.buf<double>("state", n * 7u);
+    std::vector<double> tmp(n * 7u);
+    if (n) {
+        d.chk(csc_memcpy_d2h(d.ctx, tmp.data(), d_state, n * 7u * sizeof(double)));
+    }
+    // Only the six coordinates are outputs of a step (copy_from_final_state, :1610-1630); the
+    // sizes stay the host's.
+    for (size_type i = 0; i < n; ++i) {
+        std::copy(tmp.begin() + i * 7u, tmp.begin() + i * 7u + 6u, m_state->begin() + i * 7u);
+    }
+}
+
+// append_conj_data (src/sim_propagate.cpp:1644-1701): the records of this step, sorted by time,
+// go behind the existing ones in a NEW vector (src/sim_narrow_phase.cpp:1000-1011: views of the
+// old one stay valid).
+void sim::append_conj_data(const void *recs, std::size_t n)
+{
+    static_assert(sizeof(conjunction) == sizeof(csc_conjunction), "conjunction layout");
+    auto nv = std::make_shared<std::vector<conjunction>>();
+    nv->reserve(m_det_conj->size() + n);
+    nv->insert(nv->end(), m_det_conj->begin(), m_det_conj->end());
+    const auto *src = static_cast<const conjunction *>(recs);
+    nv->insert(nv->end(), src, src + n);
+    m_det_conj = std::move(nv);
+}
+
+// dense_propagate (src/sim_propagate.cpp:1386-1503) + copy_from_final_state.
+void sim::dense_propagate(double t)
+{
+    auto &d = *m_data;
+    const auto n = static_cast<std::uint32_t>(get_nparts());
+    d.chk(csc_dense_propagate(d.ctx, n, d.order, t, d.get<std::uint64_t>("tc_row"), d.get<std::uint32_t>("nsub"),
+                              d.get<double>("tcs_xyz"), d.get<double>("tcs_vr"), d.get<double>("tcoords"),
+                              d.get<double>("final_state")));
+    const int rc = csc_check_flags(d.ctx);
+    if (rc == CSC_ERR_NO_SUBSTEPS) {
+        throw std::invalid_argument("The computation of dense_propagate() could not be performed because no timesteps "
+                                    "have been taken for a particle");
+    }
+    d.chk(rc);
+    d.chk(csc_copy_final_state(d.ctx, n, d.get<double>("final_state"), d.get<double>("state")));
+    if (d.host_sync) {
+        download_state();
+    }
+}
+
+// step(): src/sim_propagate.cpp:516-1345.
+outcome sim::step()
+{
+    auto &d = *m_data;
+    const auto nparts = get_nparts();
+    if (nparts == 0u) {
+        throw std::invalid_argument("Cannot integrate a simulation with no particles");
+    }
+    if (nparts > 0xfffffff0ull) {
+        throw std::overflow_error("Overflow detected: the number of particles does not fit 32 bits");
+    }
+    const auto n = static_cast<std::uint32_t>(nparts);
+    const std::uint32_t nchunks0 = m_n_par_ct;
+    const double delta_t0 = m_ct * nchunks0;
+    if (!std::isfinite(delta_t0) || delta_t0 <= 0) {
+        throw std::invalid_argument("An invalid superstep size of " + fmt_d(delta_t0) + " was inferred");
+    }
+    if (d.order != 20u) {
+        throw std::invalid_argument("Only tol = machine epsilon (Taylor order 20) is built into the HIP kernels, tol = "
+                                    + fmt_d(d.tol) + " needs order " + std::to_string(d.order));
+    }
+    d.ensure_ctx();
+    csc_ctx *ctx = d.ctx;
+
+    if (d.host_sync) {
+        // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
+        for (size_type i = 0; i < nparts; ++i) {
+            const double sz = (*m_state)[i * 7u + 6u];
+            if (!std::isfinite(sz) || sz < 0) {
+                throw std::invalid_argument("An invalid particle size of " + fmt_d(sz)
+                                            + " was detected for the particle at index " + std::to_string(i));
+            }
+        }
+        upload_state();
+    }
+
+    const std::size_t cn = static_cast<std::size_t>(nchunks0) * n;
+    double *d_state = d.buf<double>("state", n * 7ull);
+    auto *d_active = d.buf<std::uint8_t>("active", n);
+    auto *d_nsub = d.buf<std::uint32_t>("nsub", n);
+    auto *d_status = d.buf<std::int32_t>("status", n);
+    auto *d_ev_idx = d.buf<std::uint32_t>("ev_idx", n);
+    auto *d_ev_time = d.buf<double>("ev_time", n);
+    auto *d_nf_t = d.buf<double>("nf_last_t", n);
+    auto *d_final = d.buf<double>("final_state", n * 6ull);
+    auto *d_lbs = d.buf<float>("lbs", cn * 4u);
+    auto *d_ubs = d.buf<float>("ubs", cn * 4u);
+    auto *d_glb = d.buf<float>("glb", nchunks0 * 4ull);
+    auto *d_gub = d.buf<float>("gub", nchunks0 * 4ull);
+    auto *d_codes = d.buf<std::uint64_t>("codes", cn);
+    auto *d_vidx = d.buf<std::uint32_t>("vidx", cn);
+    auto *d_scodes = d.buf<std::uint64_t>("srt_codes", cn);
+    auto *d_slbs = d.buf<float>("srt_lbs", cn * 4u);
+    auto *d_subs = d.buf<float>("srt_ubs", cn * 4u);
+    auto *d_tc_row = d.buf<std::uint64_t>("tc_row", n);
+    float *d_recs = d.np_prefilter ? d.buf<float>("recs", cn * 16u) : nullptr;
+    float *d_srecs = d.np_prefilter ? d.buf<float>("srt_recs", cn * 16u) : nullptr;
+
+    // Activity flags (:639-647).
+    const bool with_conj = m_conj_thresh != 0;
+    const std::vector<std::uint64_t> cwl(m_coll_whitelist.begin(), m_coll_whitelist.end());
+    const std::vector<std::uint64_t> jwl(m_conj_whitelist.begin(), m_conj_whitelist.end());
+    d.chk(csc_activity_flags(ctx, n, d_state, m_min_coll_radius, with_conj ? 1 : 0, cwl.data(), cwl.size(), jwl.data(),
+                             jwl.size(), d_active));
+
+    csc_prop_cfg cfg{};
+    cfg.dyn_kind = CSC_DYN_KEPLER;
+    cfg.order = d.order;
+    cfg.mu = d.dyn.mu;
+    cfg.rhofac = std::exp(-0.7 / (d.order - 1)) / (std::exp(1.) * std::exp(1.));
+    cfg.init_time_hi = d.time.hi;
+    cfg.init_time_lo = d.time.lo;
+    cfg.delta_t = delta_t0;
+    cfg.ct = m_ct;
+    cfg.nchunks = nchunks0;
+    cfg.max_substeps = 0;
+    cfg.conj_thresh = m_conj_thresh;
+    cfg.has_exit = with_exit_event() ? 1 : 0;
+    cfg.exit_c0 = m_exit_radius * m_exit_radius;
+    cfg.has_reentry = with_reentry_event() ? 1 : 0;
+    if (const auto *ell = std::get_if<std::vector<double>>(&m_reentry_radius)) {
+        const double a = (*ell)[0], b = (*ell)[1], c = (*ell)[2];
+        cfg.reentry_k[0] = (b * c) * (b * c);
+        cfg.reentry_k[1] = (a * c) * (a * c);
+        cfg.reentry_k[2] = (a * b) * (a * b);
+        cfg.reentry_c0 = a * a * b * b * c * c;
+    } else {
+        const double r = std::get<double>(m_reentry_radius);
+        cfg.reentry_k[0] = cfg.reentry_k[1] = cfg.reentry_k[2] = 1.;
+        cfg.reentry_c0 = r * r;
+    }
+
+    d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
+    csc_prop_summary summ{};
+    d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+
+    if (summ.n_nf) {
+        // :1127-1145: nothing user-visible changes.
+        m_int_info = std::tuple<size_type, double>{summ.nf_idx, summ.nf_time};
+        return outcome::err_nf_state;
+    }
+    if (summ.flags & CSC_ST_FLAG_BAD_AABB) {
+        throw std::invalid_argument("The computation of the bounding box for a particle produced a non-finite bound");
+    }
+    if (summ.flags & CSC_ST_FLAG_BAD_TCOORD) {
+        throw std::invalid_argument("A non-finite time coordinate was generated during the numerical integration of a particle");
+    }
+    if (summ.flags & CSC_ST_FLAG_MAX_SUBSTEPS) {
+        throw std::overflow_error("Overflow detected during the numerical integration of a particle (substep cap reached)");
+    }
+
+    std::uint32_t nchunks = nchunks0;
+    double delta_t = delta_t0;
+    if (summ.n_ste) {
+        // :1148-1171
+        delta_t = std::min(summ.ste_time, delta_t0);
+        const auto new_nchunks = static_cast<std::uint32_t>(std::ceil(delta_t / m_ct));
+        if (new_nchunks == 0u) {
+            throw std::invalid_argument(
+                "The recomputed number of chunks after the triggering of a stopping terminal "
+                "event cannot be zero (this likely indicates that the simulation was restarted "
+                "without resolving a stopping terminal event)");
+        }
+        nchunks = std::min(new_nchunks, nchunks0);
+    }
+
+    d.chk(csc_global_aabb(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub));
+    d.chk(csc_morton_encode(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes));
+    d.chk(csc_sort_gather(ctx, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs));
+
+    // Taylor coefficients for dense output: CSR rows in the Morton order of chunk 0.
+    const std::uint64_t tot = summ.total_substeps;
+    std::uint32_t xs = 0, vs = 0;
+    d.chk(csc_tc_strides(d.order, &xs, &vs));
+    auto *d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(tot, 1) * xs);
+    auto *d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(tot, 1) * vs);
+    auto *d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
+    d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
+    d.chk(csc_bvh_build(ctx, n, nchunks, d_scodes, d_slbs, d_subs));
+    std::uint64_t npairs = 0;
+    d.chk(csc_broad_phase(ctx, n, nchunks, d_slbs, d_subs, d_vidx, d_active, &npairs));
+    {
+        const int rc = csc_check_flags(ctx);
+        if (rc == CSC_ERR_NONFINITE_AABB) {
+            throw std::invalid_argument("A global bounding box with non-finite boundaries and/or size was generated");
+        }
+        d.chk(rc);
+    }
+    std::uint64_t ncoll = 0, nconj = 0;
+    std::uint32_t warn = 0;
+    d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
+                           d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
+    std::vector<csc_collision> coll(ncoll);
+    std::vector<csc_conjunction> conj(nconj);
+    d.chk(csc_narrow_phase_get(ctx, coll.data(), coll.size(), conj.data(), conj.size()));
+
+    d.stats.bp_pairs = npairs;
+    d.stats.np_candidates = csc_narrow_phase_candidates(ctx);
+    d.stats.total_substeps = tot;
+    d.stats.nchunks = nchunks;
+    d.last_coll.clear();
+    for (const auto &c : coll) {
+        d.last_coll.emplace_back(c.i, c.j, c.time);
+    }
+    d.last_conj.resize(conj.size());
+    if (!conj.empty()) {
+        std::memcpy(static_cast<void *>(d.last_conj.data()), conj.data(), conj.size() * sizeof(conjunction));
+    }
+
+    // Outcome resolution (:1189-1345). coll is sorted by (time, i, j); a collision wins a tie
+    // with a terminal event (:1225).
+    outcome oc = outcome::success;
+    double interrupt_time = 0;
+    if (!coll.empty()) {
+        interrupt_time = coll[0].time;
+        oc = outcome::collision;
+    }
+    if (summ.n_ste && (oc == outcome::success || summ.ste_time < interrupt_time)) {
+        interrupt_time = summ.ste_time;
+        oc = (with_exit_event() && summ.ste_ev_idx == 0u) ? outcome::exit : outcome::reentry;
+    }
+
+    if (oc == outcome::success) {
+        d.time = df_add(d.time, dfloat{delta_t0, 0.});
+        d.chk(csc_copy_final_state(ctx, n, d_final, d_state));
+        if (d.host_sync) {
+            download_state();
+        }
+        m_int_info.reset();
+        if (with_conj) {
+            append_conj_data(conj.data(), conj.size());
+        }
+    } else {
+        dense_propagate(interrupt_time);
+        d.time = df_add(d.time, dfloat{interrupt_time, 0.});
+        if (oc == outcome::collision) {
+            m_int_info = std::array<size_type, 2>{static_cast<size_type>(coll[0].i), static_cast<size_type>(coll[0].j)};
+        } else {
+            m_int_info = static_cast<size_type>(summ.ste_idx);
+        }
+        if (with_conj) {
+            // Keep the conjunctions that happen before the interruption (:1329-1336).
+            const auto first = conj.begin();
+            const auto last = std::lower_bound(conj.begin(), conj.end(), d.time.hi,
+                                               [](const csc_conjunction &c, double t) { return c.time < t; });
+            append_conj_data(conj.data(), static_cast<std::size_t>(last - first));
+        }
+    }
+    return oc;
+}
+
+// propagate_until (src/sim_propagate.cpp:1505-1603).
+outcome sim::propagate_until(double t)
+{
+    auto &d = *m_data;
+    if (!std::isfinite(t) || df_lt(dfloat{t, 0.}, d.time)) {
+        throw std::invalid_argument("The final time passed to the propagate_until() function must be finite and not less "
+                                    "than the current simulation time, but a value of "
+                                    + fmt_d(t) + " was provided instead");
+    }
+    const dfloat final_t{t, 0.};
+    if (df_eq(final_t, d.time)) {
+        return outcome::time_limit;
+    }
+    while (true) {
+        const dfloat orig_t = d.time;
+        const outcome cur = step();
+        if (cur == outcome::success) {
+            if (!df_lt(d.time, final_t)) {
+                dense_propagate(df_sub(final_t, orig_t).hi);
+                d.time = final_t;
+                return outcome::time_limit;
+            }
+        } else if (cur != outcome::err_nf_state) {
+            if (df_lt(final_t, d.time)) {
+                // Interrupted after the final time: roll back to it (:1545-1569).
+                dense_propagate(df_sub(final_t, orig_t).hi);
+                d.time = final_t;
+                m_int_info.reset();
+                return outcome::time_limit;
+            }
+            return cur;
+        } else {
+            return cur;
+        }
+    }
+}
+
+std::ostream &operator<<(std::ostream &os, const sim &s)
+{
+    os << "Total number of particles: " << s.get_nparts() << '\n';
+    os << "Collisional timestep     : " << fmt_d(s.get_ct()) << '\n';
+    return os;
+}
+
+std::ostream &operator<<(std::ostream &os, const sim::conjunction &c)
+{
+    return os << "{" << c.i << ", " << c.j << ", " << fmt_d(c.time) << ", " << fmt_d(c.dist) << "}";
+}
+
+} // namespace cascade

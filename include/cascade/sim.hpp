@@ -1,0 +1,365 @@
+// include/cascade/sim.hpp
+//
+// Public C++ API of the MI355X build: cascade::sim with the names, argument meaning and
+// error behaviour of the reference class (esa/cascade include/cascade/sim.hpp:82-513), driving
+// the gfx950 kernels of libcascade_hip.so through the C ABI of include/cascade_hip.h.
+//
+// Drop-in surface: outcome, sim::conjunction, sim::whitelist_t, the named constructor
+// arguments kw::dyn / pars / reentry_radius / exit_radius / tol / high_accuracy /
+// compact_mode / n_par_ct / conj_thresh / min_coll_radius / coll_whitelist / conj_whitelist,
+// step(), propagate_until(), every getter and setter, set_new_state_pars(),
+// remove_particles(), reset_conjunctions(), the _get_*_ptr() accessors used by the Python
+// bindings, operator<<.
+//
+// The single intentional deviation: kw::dyn takes a cascade::dynamics::dyn_t descriptor
+// (dynamics::kepler(mu)) instead of a vector of heyoka expressions; heyoka and its LLVM JIT are
+// replaced by built-in dynamics integrated on the GPU. One extra named
+// argument, kw::device, selects the GPU.
+//
+// No CPU fallback: step() needs libcascade_hip.so and a HIP device and throws
+// std::runtime_error otherwise. Construction, validation, getters and setters work anywhere.
+#ifndef CASCADE_SIM_HPP
+#define CASCADE_SIM_HPP
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <iosfwd>
+#include <iterator>
+#include <memory>
+#include <optional>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <unordered_set>
+#include <utility>
+#include <variant>
+#include <vector>
+
+namespace cascade
+{
+
+// include/cascade/sim.hpp:82
+enum class outcome { success, time_limit, collision, reentry, exit, err_nf_state };
+
+namespace dynamics
+{
+
+// Built-in dynamics descriptor (replaces std::vector<std::pair<heyoka::expression,
+// heyoka::expression>>, sim.hpp:213-222).
+struct dyn_t {
+    enum kind_t : int { kepler = 0 };
+    kind_t kind = kepler;
+    double mu = 1.;
+    std::uint32_t npars = 0;
+
+    friend bool operator==(const dyn_t &a, const dyn_t &b)
+    {
+        return a.kind == b.kind && a.mu == b.mu && a.npars == b.npars;
+    }
+};
+
+// src/sim_dynamics.cpp:25-42
+dyn_t kepler(double mu = 1.);
+
+} // namespace dynamics
+
+namespace detail
+{
+
+template <typename Tag, typename T>
+struct tagged_arg {
+    T value;
+};
+
+template <typename Tag>
+struct kwarg {
+    template <typename T>
+    constexpr tagged_arg<Tag, std::decay_t<T>> operator=(T &&v) const
+    {
+        return {std::forward<T>(v)};
+    }
+};
+
+} // namespace detail
+
+// Named constructor arguments (sim.hpp:56-72): sim(state, ct, kw::n_par_ct = 3, ...).
+namespace kw
+{
+
+inline constexpr detail::kwarg<struct dyn_tag> dyn{};
+inline constexpr detail::kwarg<struct pars_tag> pars{};
+inline constexpr detail::kwarg<struct reentry_radius_tag> reentry_radius{};
+inline constexpr detail::kwarg<struct exit_radius_tag> exit_radius{};
+inline constexpr detail::kwarg<struct tol_tag> tol{};
+inline constexpr detail::kwarg<struct high_accuracy_tag> high_accuracy{};
+inline constexpr detail::kwarg<struct compact_mode_tag> compact_mode{};
+inline constexpr detail::kwarg<struct n_par_ct_tag> n_par_ct{};
+inline constexpr detail::kwarg<struct conj_thresh_tag> conj_thresh{};
+inline constexpr detail::kwarg<struct min_coll_radius_tag> min_coll_radius{};
+inline constexpr detail::kwarg<struct coll_whitelist_tag> coll_whitelist{};
+inline constexpr detail::kwarg<struct conj_whitelist_tag> conj_whitelist{};
+inline constexpr detail::kwarg<struct device_tag> device{};
+
+} // namespace kw
+
+class sim
+{
+public:
+    using size_type = std::vector<double>::size_type;
+
+    // sim.hpp:90-104 (numpy dtype: cascade.py/core.cpp:81)
+    struct conjunction {
+        size_type i = 0;
+        size_type j = 0;
+        double time = 0;
+        double dist = 0;
+        std::array<double, 6> state_i = {};
+        std::array<double, 6> state_j = {};
+    };
+
+    using whitelist_t = std::unordered_set<size_type>;
+    using interrupt_info_t
+        = std::optional<std::variant<std::array<size_type, 2>, size_type, std::tuple<size_type, double>>>;
+
+    // Everything the named arguments can set (defaults = the reference's, sim.hpp:200-379).
+    struct options {
+        dynamics::dyn_t dyn = dynamics::dyn_t{};
+        std::vector<double> pars;
+        std::variant<double, std::vector<double>> reentry_radius = 0.;
+        double exit_radius = 0.;
+        double tol = 0.; // 0: machine epsilon
+        bool high_accuracy = false;
+        bool compact_mode = false;
+        std::uint32_t n_par_ct = 1;
+        double conj_thresh = 0.;
+        double min_coll_radius = 0.;
+        whitelist_t coll_whitelist, conj_whitelist;
+        int device = 0;
+    };
+
+    // Measurements of the last step() (no counterpart in the reference besides its trace log).
+    struct step_stats {
+        std::uint64_t bp_pairs = 0;       // AABB pairs found by the broad phase
+        std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
+        std::uint64_t total_substeps = 0; // Taylor substeps of all particles
+        std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)
+    };
+
+private:
+    struct sim_data;
+
+    std::shared_ptr<std::vector<double>> m_state;
+    std::shared_ptr<std::vector<double>> m_pars;
+    double m_ct = 0;
+    std::uint32_t m_n_par_ct = 0;
+    interrupt_info_t m_int_info;
+    std::variant<double, std::vector<double>> m_reentry_radius;
+    double m_exit_radius = 0;
+    std::uint32_t m_npars = 0;
+    double m_conj_thresh = 0;
+    std::shared_ptr<std::vector<conjunction>> m_det_conj;
+    double m_min_coll_radius = 0;
+    whitelist_t m_coll_whitelist, m_conj_whitelist;
+    std::unique_ptr<sim_data> m_data;
+
+    struct ptag_t {
+    };
+    sim(ptag_t, std::vector<double>, double);
+    void finalise_ctor(options);
+
+    template <typename Tag, typename T>
+    static void apply_kwarg(options &, detail::tagged_arg<Tag, T> &&);
+
+    [[nodiscard]] bool with_reentry_event() const;
+    [[nodiscard]] bool with_exit_event() const;
+    void verify_state_vector(const std::vector<double> &) const;
+    void validate_pars_vector(std::vector<double> &, size_type) const;
+    void dense_propagate(double);
+    void append_conj_data(const void *, std::size_t);
+
+public:
+    sim();
+    template <typename... KwArgs>
+    explicit sim(std::vector<double> state, double ct, KwArgs &&...kw_args) : sim(ptag_t{}, std::move(state), ct)
+    {
+        options o;
+        (apply_kwarg(o, std::forward<KwArgs>(kw_args)), ...);
+        finalise_ctor(std::move(o));
+    }
+    explicit sim(std::vector<double> state, double ct, options o) : sim(ptag_t{}, std::move(state), ct)
+    {
+        finalise_ctor(std::move(o));
+    }
+    sim(const sim &);
+    sim(sim &&) noexcept;
+    ~sim();
+    sim &operator=(const sim &);
+    sim &operator=(sim &&) noexcept;
+
+    [[nodiscard]] const interrupt_info_t &get_interrupt_info() const
+    {
+        return m_int_info;
+    }
+    [[nodiscard]] const std::vector<double> &get_state() const
+    {
+        return *m_state;
+    }
+    [[nodiscard]] const double *get_state_data() const
+    {
+        return m_state->data();
+    }
+    [[nodiscard]] double *get_state_data()
+    {
+        return m_state->data();
+    }
+    [[nodiscard]] const std::vector<double> &get_pars() const
+    {
+        return *m_pars;
+    }
+    [[nodiscard]] const double *get_pars_data() const
+    {
+        return m_pars->data();
+    }
+    [[nodiscard]] double *get_pars_data()
+    {
+        return m_pars->data();
+    }
+    [[nodiscard]] size_type get_nparts() const
+    {
+        return get_state().size() / 7u;
+    }
+
+    [[nodiscard]] double get_time() const;
+    void set_time(double);
+    [[nodiscard]] double get_ct() const;
+    void set_ct(double);
+    [[nodiscard]] std::uint32_t get_n_par_ct() const;
+    void set_n_par_ct(std::uint32_t);
+    [[nodiscard]] double get_tol() const;
+    [[nodiscard]] bool get_high_accuracy() const;
+    [[nodiscard]] bool get_compact_mode() const;
+    [[nodiscard]] std::uint32_t get_npars() const;
+    [[nodiscard]] std::variant<double, std::vector<double>> get_reentry_radius() const;
+    [[nodiscard]] double get_exit_radius() const
+    {
+        return m_exit_radius;
+    }
+    [[nodiscard]] double get_conj_thresh() const
+    {
+        return m_conj_thresh;
+    }
+    void set_conj_thresh(double);
+    [[nodiscard]] const std::vector<conjunction> &get_conjunctions() const
+    {
+        return *m_det_conj;
+    }
+    void reset_conjunctions();
+    [[nodiscard]] double get_min_coll_radius() const
+    {
+        return m_min_coll_radius;
+    }
+    void set_min_coll_radius(double);
+    [[nodiscard]] const whitelist_t &get_coll_whitelist() const
+    {
+        return m_coll_whitelist;
+    }
+    void set_coll_whitelist(whitelist_t);
+    [[nodiscard]] const whitelist_t &get_conj_whitelist() const
+    {
+        return m_conj_whitelist;
+    }
+    void set_conj_whitelist(whitelist_t);
+
+    void set_new_state_pars(std::vector<double>, std::vector<double> = {});
+    void remove_particles(std::vector<size_type>);
+
+    outcome step();
+    outcome propagate_until(double);
+
+    [[nodiscard]] std::shared_ptr<std::vector<double>> _get_state_ptr() const
+    {
+        return m_state;
+    }
+    [[nodiscard]] std::shared_ptr<std::vector<double>> _get_pars_ptr() const
+    {
+        return m_pars;
+    }
+    [[nodiscard]] std::shared_ptr<std::vector<conjunction>> _get_conjunctions_ptr() const
+    {
+        return m_det_conj;
+    }
+
+    // ---- additions of this build (not in the reference) -------------------------------
+    [[nodiscard]] const dynamics::dyn_t &get_dyn() const;
+    [[nodiscard]] int get_device() const;
+    // The host state is the source of truth at every step() entry and exit (the Python bindings
+    // hand out writable views of it, cascade.py/core.cpp:199-230). With host_sync off the state
+    // stays resident in HBM between steps: upload_state() once, download_state() when needed.
+    void set_host_sync(bool);
+    [[nodiscard]] bool get_host_sync() const;
+    void upload_state();
+    void download_state();
+    // Geometric pre-filter in front of the polynomial narrow phase (on by default; it never
+    // changes the detected events, see k_np_prefilter).
+    void set_np_prefilter(bool);
+    [[nodiscard]] bool get_np_prefilter() const;
+    [[nodiscard]] const step_stats &get_step_stats() const;
+    // Measurement aid: node AABB tests the reference's per-particle traversal would perform on
+    // the trees of the last step() (the unit count behind the broad phase's algorithmic bytes).
+    [[nodiscard]] std::uint64_t bp_nodes_visited();
+    // Collisions (i, j, time relative to the superstep start) and conjunctions found by the
+    // last step(), before the outcome logic discards any of them.
+    [[nodiscard]] const std::vector<std::tuple<size_type, size_type, double>> &get_last_collisions() const;
+    [[nodiscard]] const std::vector<conjunction> &get_last_step_conjunctions() const;
+    // The C-ABI context (csc_ctx *) of this simulation, created by the first step() (or by this
+    // call); for profiling and measurement.
+    [[nodiscard]] void *_get_hip_context();
+};
+
+std::ostream &operator<<(std::ostream &, const sim &);
+std::ostream &operator<<(std::ostream &, const sim::conjunction &);
+
+// ---- named-argument plumbing ---------------------------------------------------------
+
+template <typename Tag, typename T>
+inline void sim::apply_kwarg(options &o, detail::tagged_arg<Tag, T> &&a)
+{
+    if constexpr (std::is_same_v<Tag, kw::dyn_tag>) {
+        o.dyn = std::move(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::pars_tag>) {
+        o.pars = std::vector<double>(std::begin(a.value), std::end(a.value));
+    } else if constexpr (std::is_same_v<Tag, kw::reentry_radius_tag>) {
+        if constexpr (std::is_arithmetic_v<T>) {
+            o.reentry_radius = static_cast<double>(a.value);
+        } else {
+            o.reentry_radius = std::vector<double>(std::begin(a.value), std::end(a.value));
+        }
+    } else if constexpr (std::is_same_v<Tag, kw::exit_radius_tag>) {
+        o.exit_radius = static_cast<double>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::tol_tag>) {
+        o.tol = static_cast<double>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::high_accuracy_tag>) {
+        o.high_accuracy = static_cast<bool>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::compact_mode_tag>) {
+        o.compact_mode = static_cast<bool>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::n_par_ct_tag>) {
+        o.n_par_ct = static_cast<std::uint32_t>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::conj_thresh_tag>) {
+        o.conj_thresh = static_cast<double>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::min_coll_radius_tag>) {
+        o.min_coll_radius = static_cast<double>(a.value);
+    } else if constexpr (std::is_same_v<Tag, kw::coll_whitelist_tag>) {
+        o.coll_whitelist = whitelist_t(std::begin(a.value), std::end(a.value));
+    } else if constexpr (std::is_same_v<Tag, kw::conj_whitelist_tag>) {
+        o.conj_whitelist = whitelist_t(std::begin(a.value), std::end(a.value));
+    } else if constexpr (std::is_same_v<Tag, kw::device_tag>) {
+        o.device = static_cast<int>(a.value);
+    } else {
+        static_assert(sizeof(T) == 0, "unknown named argument");
+    }
+}
+
+} // namespace cascade
+
+#endif
