@@ -10,9 +10,12 @@ with the state already resident in HBM.
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, each rank runs the full pipeline on its OWN 1M-object
-population (seed 42 + rank): independent replicas, weak scaling, no data-path collective
-(the cross-GPU exchange of the north star is not built yet).
+N > 1: one process per GPU, ONE 1M-object simulation sharded over the N GPUs (strong
+scaling): every rank propagates all objects and builds the whole BVH (cheaper than moving the
+boxes over xGMI at this size), walks it for its share of the query objects, runs the narrow
+phase on its pairs, and the per-step event lists are all-gathered with RCCL
+(cascade_amd/parallel.py). --mode replicas runs N independent
+simulations instead (weak scaling, no collective).
 
 Prints ONE JSON line (rank 0) with the contract fields plus "roofline" (dominant kernel,
 algorithmic bytes / HIP-event kernel time) and, at N = 1, "cpu_baseline" (the CPU oracle,
@@ -72,6 +75,7 @@ def main():
     ap.add_argument("--n-par-ct", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,16 +86,26 @@ def main():
         import torch
         import torch.distributed as dist_
 
+        # "nccl" is RCCL on ROCm. CSC_DIST_BACKEND=gloo lets a one-GPU box rehearse the
+        # multi-process path (all ranks on the same device).
+        backend = os.environ.get("CSC_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist_.init_process_group(backend="nccl")
+        dist_.init_process_group(backend=backend)
         dist = dist_
+        tdev = "cuda" if backend == "nccl" else "cpu"
 
     from cascade_amd import _capi, sim
     from cascade_amd.workloads import random_leo_pop_kep
 
     N = args.nparts
-    st = random_leo_pop_kep(N, seed=42 + rank)
+    sharded = world > 1 and args.mode == "sharded"
+    st = random_leo_pop_kep(N, seed=42 if (sharded or world == 1) else 42 + rank)
     s = sim(st, args.ct, n_par_ct=args.n_par_ct, device=local_rank)
+    if sharded:
+        from cascade_amd.parallel import shard
+
+        shard(s)
     s.host_sync = False  # state stays resident in HBM between steps
     s.upload_state()
     ctx = _capi.Context.from_handle(s._hip_context)  # the simulation's C-ABI context (profiling only)
@@ -129,12 +143,18 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max = float(t.item())
-        od = torch.tensor([tot_obj_days], dtype=torch.float64, device="cuda")
-        dist.all_reduce(od, op=dist.ReduceOp.SUM)
-        tot_obj_days = float(od.item())
+        if not sharded:
+            od = torch.tensor([tot_obj_days], dtype=torch.float64, device=tdev)
+            dist.all_reduce(od, op=dist.ReduceOp.SUM)
+            tot_obj_days = float(od.item())
+        pr = torch.tensor([float(pairs)], dtype=torch.float64, device=tdev)
+        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+        pairs_all = float(pr.item())
+    else:
+        pairs_all = float(pairs)
 
     if rank != 0:
         if dist is not None:
@@ -148,7 +168,10 @@ def main():
     dom = max(kern, key=lambda k: kern[k][1])
     # Units of the last step (populations change slowly; the counts of all steps agree to <0.1 %).
     units = dict(n=N, nchunks=args.n_par_ct, substeps=s.last_total_substeps, pairs=pairs / args.steps, pair_intervals=pairs / args.steps * max(1.0, s.last_total_substeps / (N * args.n_par_ct)), sort_keys=N * args.n_par_ct, bp_nodes_visited=s.bp_nodes_visited())
-    workload = "random_leo_pop_kep scaled to %d objects per GPU (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, args.ct, args.n_par_ct)
+    if sharded:
+        workload = "random_leo_pop_kep scaled to %d objects, one simulation over %d GPUs (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42)" % (N, world, args.ct, args.n_par_ct)
+    else:
+        workload = "random_leo_pop_kep scaled to %d objects per GPU (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, args.ct, args.n_par_ct)
 
     def roofline_of(name):
         launches, ms = kern[name]
@@ -177,7 +200,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall_max / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -186,7 +209,8 @@ def main():
             "nparts_per_gpu": N,
             "ct": args.ct,
             "n_par_ct": args.n_par_ct,
-            "parallelism": "replicas x%d" % world,
+            "parallelism": ("one simulation, queries sharded x%d (replicated propagation / sort / BVH, events all-gathered over RCCL)" % world) if sharded else "replicas x%d" % world,
+            "bp_pairs_per_step_all_ranks": pairs_all / args.steps,
             "outcomes": outcomes,
             "bp_pairs_per_step": pairs / args.steps,
             "sim_time_advanced_TU": sim_time,

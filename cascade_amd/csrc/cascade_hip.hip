@@ -56,6 +56,7 @@ struct csc_ctx {
     const uint2 *bp_order = nullptr; // group-major {block, time chunk} list of the last broad phase
     const uint32_t *bp_vidx = nullptr; // the permutation the pair positions refer to
     uint32_t bp_n = 0, bp_chunks = 0;
+    uint32_t shard_rank = 0, shard_n = 1; // query sharding of the broad phase (csc_set_shard)
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
@@ -865,6 +866,16 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
 
 // ---- K6 --------------------------------------------------------------------------------
 
+int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
+{
+    if (nranks == 0u || rank >= nranks) {
+        return ctx->invalid("invalid shard (rank, nranks)");
+    }
+    ctx->shard_rank = rank;
+    ctx->shard_n = nranks;
+    return CSC_OK;
+}
+
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs)
 {
@@ -892,7 +903,12 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     q.active = d_active;
     q.counter = ctx->d_bp_counter;
     q.err_flag = ctx->d_flags + 2;
-    const uint32_t ngroups = cdiv(n, 64);
+    // Query groups of this process (all of them when there is one process).
+    const uint32_t ngroups_all = cdiv(n, 64);
+    const uint32_t ngroups = cdiv(ngroups_all, csc::BP_SHARD_RUN * ctx->shard_n) * csc::BP_SHARD_RUN;
+    q.shard_rank = ctx->shard_rank;
+    q.shard_n = ctx->shard_n;
+    q.ngroups = ngroups_all;
     const uint32_t nlists = ngroups * nchunks;
     const dim3 grid(ngroups, nchunks), blk(64);
     CSC_BUF(d_head, int32_t, "bp_head", nlists);

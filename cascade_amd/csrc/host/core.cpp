@@ -18,6 +18,7 @@
 #include <variant>
 #include <vector>
 
+#include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -216,6 +217,36 @@ PYBIND11_MODULE(core, m)
         .def_property("host_sync", &sim::get_host_sync, &sim::set_host_sync)
         .def_property("np_prefilter", &sim::get_np_prefilter, &sim::set_np_prefilter)
         .def("bp_nodes_visited", &sim::bp_nodes_visited)
+        .def(
+            "set_shard",
+            [](sim &s, std::uint32_t rank, std::uint32_t nranks, py::object exchange) {
+                // exchange(coll, conj) -> (coll, conj): numpy record arrays in, merged arrays out.
+                sim::exchange_t fn;
+                if (!exchange.is_none()) {
+                    fn = [exchange](std::vector<sim::collision_t> &coll, std::vector<sim::conjunction> &conj) {
+                        py::gil_scoped_acquire gil;
+                        py::array_t<coll_rec> c_in(static_cast<py::ssize_t>(coll.size()));
+                        auto *cp = static_cast<coll_rec *>(c_in.mutable_data());
+                        for (std::size_t k = 0; k < coll.size(); ++k) {
+                            cp[k] = coll_rec{std::get<0>(coll[k]), std::get<1>(coll[k]), std::get<2>(coll[k])};
+                        }
+                        py::array_t<sim::conjunction> j_in(static_cast<py::ssize_t>(conj.size()));
+                        std::copy(conj.begin(), conj.end(), static_cast<sim::conjunction *>(j_in.mutable_data()));
+                        const py::tuple out = exchange(c_in, j_in);
+                        const auto c_out = out[0].cast<py::array_t<coll_rec, py::array::c_style | py::array::forcecast>>();
+                        const auto j_out
+                            = out[1].cast<py::array_t<sim::conjunction, py::array::c_style | py::array::forcecast>>();
+                        coll.resize(static_cast<std::size_t>(c_out.size()));
+                        for (std::size_t k = 0; k < coll.size(); ++k) {
+                            const coll_rec &r = c_out.data()[k];
+                            coll[k] = sim::collision_t{r.i, r.j, r.time};
+                        }
+                        conj.assign(j_out.data(), j_out.data() + j_out.size());
+                    };
+                }
+                s.set_shard(rank, nranks, std::move(fn));
+            },
+            "rank"_a, "nranks"_a, "exchange"_a = py::none{})
         .def("upload_state", &sim::upload_state)
         .def("download_state", &sim::download_state)
         .def_property_readonly("last_bp_pairs", [](const sim &s) { return s.get_step_stats().bp_pairs; })

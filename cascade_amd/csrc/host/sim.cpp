@@ -126,6 +126,8 @@ struct sim::sim_data {
     int device = 0;
     dfloat time;
     bool host_sync = true, np_prefilter = true;
+    std::uint32_t shard_rank = 0, shard_n = 1;
+    exchange_t exchange;
     step_stats stats;
     std::vector<std::tuple<size_type, size_type, double>> last_coll;
     std::vector<conjunction> last_conj;
@@ -141,7 +143,8 @@ struct sim::sim_data {
     // A copy shares nothing on the device: it gets its own context on its first step().
     sim_data(const sim_data &o)
         : dyn(o.dyn), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
-          device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter)
+          device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
+          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange)
     {
     }
     ~sim_data()
@@ -549,6 +552,19 @@ bool sim::get_host_sync() const
     return m_data->host_sync;
 }
 
+void sim::set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchange)
+{
+    if (nranks == 0u || rank >= nranks) {
+        throw std::invalid_argument("Invalid shard: rank " + std::to_string(rank) + " of " + std::to_string(nranks));
+    }
+    if (nranks > 1u && !exchange) {
+        throw std::invalid_argument("A sharded simulation needs an event exchange function");
+    }
+    m_data->shard_rank = rank;
+    m_data->shard_n = nranks;
+    m_data->exchange = std::move(exchange);
+}
+
 void sim::set_np_prefilter(bool v)
 {
     m_data->np_prefilter = v;
@@ -794,6 +810,7 @@ outcome sim::step()
     d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
     d.chk(csc_bvh_build(ctx, n, nchunks, d_scodes, d_slbs, d_subs));
     std::uint64_t npairs = 0;
+    d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));
     d.chk(csc_broad_phase(ctx, n, nchunks, d_slbs, d_subs, d_vidx, d_active, &npairs));
     {
         const int rc = csc_check_flags(ctx);
@@ -821,6 +838,19 @@ outcome sim::step()
     d.last_conj.resize(conj.size());
     if (!conj.empty()) {
         std::memcpy(static_cast<void *>(d.last_conj.data()), conj.data(), conj.size() * sizeof(conjunction));
+    }
+    if (d.shard_n > 1u) {
+        // Merge the event lists of all processes; from here on every process works on the same
+        // data (the propagation results are identical everywhere by construction).
+        d.exchange(d.last_coll, d.last_conj);
+        coll.resize(d.last_coll.size());
+        for (std::size_t k = 0; k < coll.size(); ++k) {
+            coll[k] = csc_collision{std::get<0>(d.last_coll[k]), std::get<1>(d.last_coll[k]), std::get<2>(d.last_coll[k])};
+        }
+        conj.resize(d.last_conj.size());
+        if (!conj.empty()) {
+            std::memcpy(static_cast<void *>(conj.data()), d.last_conj.data(), conj.size() * sizeof(conjunction));
+        }
     }
 
     // Outcome resolution (:1189-1345). coll is sorted by (time, i, j); a collision wins a tie

@@ -486,6 +486,10 @@ struct bp_params {
     unsigned long long *counter; // [1] statistics (diagnostic kernel)
     int *err_flag;               // traversal stack overflow (cannot happen for depth <= 64)
     std::uint32_t *gstats;       // debug builds: per group {nodes visited, cycles}
+    // Query sharding across GPUs: this process walks the tree for the query groups dealt to
+    // shard_rank (runs of BP_SHARD_RUN consecutive groups, round-robin over shard_n processes);
+    // every process holds the whole tree. ngroups = all groups of a chunk.
+    std::uint32_t shard_rank, shard_n, ngroups;
 };
 
 // Closed-interval overlap on the 4 dimensions (src/sim_broad_phase.cpp:149-151). Written with
@@ -510,6 +514,7 @@ CSC_DEV bool bp_overlap(const float4 &plb, const float4 &pub, const float4 &nl, 
 }
 
 constexpr int BPG_STACK = 768; // pending internal nodes of one wave
+constexpr unsigned BP_SHARD_RUN = 16; // consecutive query groups that stay on one process
 constexpr int BPG_PAIRQ = PB_SIZE + 64; // staged pairs of one wave: one pair block + one emission
 
 // tn is passed on its own (not inside bp_params) so that it can carry __restrict__: with the
@@ -524,7 +529,13 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     const std::uint32_t lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const std::uint32_t c = lin / gridDim.x;
     const int lane = threadIdx.x;
-    const std::uint32_t pidx = (lin % gridDim.x) * 64u + lane;
+    // Local group -> global group of 64 Morton-consecutive queries (identity for one process).
+    const std::uint32_t kloc = lin % gridDim.x;
+    const std::uint32_t grp = ((kloc / BP_SHARD_RUN) * q.shard_n + q.shard_rank) * BP_SHARD_RUN + kloc % BP_SHARD_RUN;
+    if (grp >= q.ngroups) {
+        return;
+    }
+    const std::uint32_t pidx = grp * 64u + lane;
     const bool valid = pidx < q.n;
     const std::size_t po = static_cast<std::size_t>(c) * q.n;
     const std::size_t no = static_cast<std::size_t>(c) * q.nn_max;

@@ -24,6 +24,7 @@
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <iosfwd>
 #include <iterator>
 #include <memory>
@@ -300,6 +301,18 @@ public:
     [[nodiscard]] bool get_host_sync() const;
     void upload_state();
     void download_state();
+    // Multi-GPU operation (no counterpart in the reference, which is single-process): `nranks`
+    // processes, one per GPU, hold the SAME simulation (same state, same calls). Each propagates
+    // every particle and builds the whole tree (cheaper than moving the boxes over xGMI at these
+    // sizes), walks it only for its share of the query particles and runs the narrow phase on
+    // the pairs it found; `exchange` then merges the per-process collision and conjunction lists
+    // (it receives the local lists, both sorted by (time, i, j), and must return the merged
+    // lists in the same order, identical on every process -- see cascade_amd/parallel.py for
+    // the torch.distributed implementation), after which every process applies the reference's
+    // outcome logic to the same data and stays in lockstep.
+    using collision_t = std::tuple<size_type, size_type, double>;
+    using exchange_t = std::function<void(std::vector<collision_t> &, std::vector<conjunction> &)>;
+    void set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchange);
     // Geometric pre-filter in front of the polynomial narrow phase (on by default; it never
     // changes the detected events, see k_np_prefilter).
     void set_np_prefilter(bool);

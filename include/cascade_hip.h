@@ -213,6 +213,13 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
  * Synchronises (the totals are read back); *n_pairs = total over chunks. */
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs);
+/* Multi-GPU query sharding (no counterpart in the reference, which is single-process): every
+ * process holds the whole tree, and csc_broad_phase walks it only for the query groups dealt
+ * to `rank` (runs of 16 groups of 64 Morton-consecutive particles, round-robin over `nranks`).
+ * A pair (i < j) is reported by the walk of query i only, hence by exactly one process; the
+ * union over the processes is the full pair set. The narrow phase then works on the local
+ * pairs. Default (0, 1). */
+int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks);
 /* Diagnostic (measurement only): re-runs the traversal of the last csc_broad_phase without
  * writing pairs and returns the number of node AABB tests, i.e. the reference's "nodes
  * visited" (every node popped from the stack of src/sim_broad_phase.cpp:121-196), summed over
