@@ -40,6 +40,13 @@ class PropCfg(C.Structure):
         ("has_reentry", C.c_int32),
         ("reentry_k", C.c_double * 3),
         ("reentry_c0", C.c_double),
+        ("J2", C.c_double),
+        ("Re", C.c_double),
+        ("dens_alpha", C.c_double * 4),
+        ("dens_beta", C.c_double * 4),
+        ("dens_gamma", C.c_double * 4),
+        ("d_pars", C.c_void_p),
+        ("npars", C.c_uint32),
     ]
 
 

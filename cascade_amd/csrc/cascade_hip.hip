@@ -329,7 +329,39 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
     }
     p.re_c0 = cfg->reentry_c0;
     p.max_substeps = cfg->max_substeps ? cfg->max_substeps : (1u << 20);
+    p.kj2 = 1.5 * cfg->J2 * cfg->mu * cfg->Re * cfg->Re;
+    p.Re = cfg->Re;
+    for (int i = 0; i < 4; ++i) {
+        p.dens_alpha[i] = cfg->dens_alpha[i];
+        p.dens_beta[i] = cfg->dens_beta[i];
+        p.dens_gamma[i] = cfg->dens_gamma[i];
+    }
+    p.pars = cfg->d_pars;
+    p.npars = cfg->npars;
     return p;
+}
+
+template <bool STORE>
+void launch_propagate(int dyn, bool events, dim3 grid, dim3 block, hipStream_t stream, const csc::prop_params &p)
+{
+#define CSC_PROP_CASE(D)                                                                                               \
+    if (events) {                                                                                                      \
+        hipLaunchKernelGGL((csc::k_propagate<20, true, STORE, D>), grid, block, 0, stream, p);                         \
+    } else {                                                                                                           \
+        hipLaunchKernelGGL((csc::k_propagate<20, false, STORE, D>), grid, block, 0, stream, p);                        \
+    }
+    switch (dyn) {
+        case 0:
+            CSC_PROP_CASE(0)
+            break;
+        case 1:
+            CSC_PROP_CASE(1)
+            break;
+        default:
+            CSC_PROP_CASE(3)
+            break;
+    }
+#undef CSC_PROP_CASE
 }
 
 int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
@@ -341,9 +373,12 @@ int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
         ctx->err = "only Taylor order 20 (tol = DBL_EPSILON) is built";
         return CSC_ERR_UNSUPPORTED;
     }
-    if (cfg->dyn_kind != CSC_DYN_KEPLER) {
-        ctx->err = "unknown dynamics kind";
+    if (cfg->dyn_kind != CSC_DYN_KEPLER && cfg->dyn_kind != CSC_DYN_J2 && cfg->dyn_kind != (CSC_DYN_J2 | CSC_DYN_DRAG)) {
+        ctx->err = "unknown dynamics kind (built: Kepler, Kepler + J2, Kepler + J2 + drag)";
         return CSC_ERR_UNSUPPORTED;
+    }
+    if ((cfg->dyn_kind & CSC_DYN_DRAG) && (cfg->d_pars == nullptr || cfg->npars == 0u)) {
+        return ctx->invalid("drag needs the runtime parameter array (BSTAR)");
     }
     if (cfg->nchunks == 0u || !(cfg->delta_t > 0) || !(cfg->ct > 0)) {
         return ctx->invalid("invalid superstep configuration");
@@ -563,11 +598,7 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
     p.recs = d_recs;
     const bool events = cfg->has_exit || cfg->has_reentry;
     const dim3 grid(cdiv(n, 64)), block(64);
-    if (events) {
-        KT("k_propagate", hipLaunchKernelGGL((csc::k_propagate<20, true, false>), grid, block, 0, ctx->stream, p));
-    } else {
-        KT("k_propagate", hipLaunchKernelGGL((csc::k_propagate<20, false, false>), grid, block, 0, ctx->stream, p));
-    }
+    KT("k_propagate", launch_propagate<false>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -602,11 +633,7 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
     p.tcoords = d_tcoords;
     const bool events = cfg->has_exit || cfg->has_reentry;
     const dim3 grid(cdiv(n, 64)), block(64);
-    if (events) {
-        KT("k_propagate_store", hipLaunchKernelGGL((csc::k_propagate<20, true, true>), grid, block, 0, ctx->stream, p));
-    } else {
-        KT("k_propagate_store", hipLaunchKernelGGL((csc::k_propagate<20, false, true>), grid, block, 0, ctx->stream, p));
-    }
+    KT("k_propagate_store", launch_propagate<true>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }

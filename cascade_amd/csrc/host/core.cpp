@@ -97,13 +97,20 @@ PYBIND11_MODULE(core, m)
     py::class_<dynamics::dyn_t>(m, "dyn_t")
         .def_readonly("mu", &dynamics::dyn_t::mu)
         .def_readonly("npars", &dynamics::dyn_t::npars)
-        .def_property_readonly("kind", [](const dynamics::dyn_t &d) { return static_cast<int>(d.kind); })
+        .def_readonly("J2", &dynamics::dyn_t::J2)
+        .def_readonly("Re", &dynamics::dyn_t::Re)
+        .def_readonly("dens_alpha", &dynamics::dyn_t::dens_alpha)
+        .def_readonly("dens_beta", &dynamics::dyn_t::dens_beta)
+        .def_readonly("dens_gamma", &dynamics::dyn_t::dens_gamma)
+        .def_property_readonly("kind", [](const dynamics::dyn_t &d) { return d.kind; })
         .def("__repr__", [](const dynamics::dyn_t &d) {
             std::ostringstream oss;
-            oss << "kepler(mu=" << d.mu << ")";
+            oss << "dynamics(kepler mu=" << d.mu << ((d.kind & 1) ? ", J2" : "") << ((d.kind & 2) ? ", drag" : "") << ")";
             return oss.str();
         });
     m.def("_kepler", &dynamics::kepler, "mu"_a = 1.);
+    m.def("_simple_earth", &dynamics::simple_earth, "J2"_a = true, "J3"_a = false, "J4"_a = false, "C22S22"_a = true,
+          "sun"_a = false, "moon"_a = false, "SRP"_a = false, "drag"_a = true, "thermonets"_a = false);
 
     py::enum_<outcome>(m, "outcome")
         .value("success", outcome::success)

@@ -38,6 +38,39 @@ dyn_t kepler(double mu)
     return d;
 }
 
+dyn_t simple_earth(bool J2, bool J3, bool J4, bool C22S22, bool sun, bool moon, bool SRP, bool drag, bool thermonets)
+{
+    const std::pair<bool, const char *> missing[] = {{J3, "J3"},   {J4, "J4"},   {C22S22, "C22S22"},        {sun, "sun"},
+                                                     {moon, "moon"}, {SRP, "SRP"}, {thermonets, "thermonets"}};
+    for (const auto &[on, name] : missing) {
+        if (on) {
+            throw std::invalid_argument(std::string("simple_earth(): the term '") + name
+                                        + "' is not built into the HIP kernels (available: J2, drag)");
+        }
+    }
+    if (drag && !J2) {
+        throw std::invalid_argument("simple_earth(): drag without J2 is not built into the HIP kernels");
+    }
+    // Constants of _simple_earth.py:136-166 (SI units).
+    dyn_t d;
+    d.mu = 3.986004407799724e5 * 1e9;
+    d.Re = 6378.1363 * 1000;
+    d.kind = dyn_t::kepler;
+    if (J2) {
+        d.kind |= dyn_t::j2;
+        d.J2 = 0.1082635854 * 1e-2;
+    }
+    if (drag) {
+        d.kind |= dyn_t::drag;
+        d.npars = 1;
+        // The fitted density constants (_simple_earth.py:24-44): beta per metre, gamma in metres.
+        d.dens_alpha = {1.01709935e-06, 7.86443375e-01, 7.50341883e-09, 8.63934252e-14};
+        d.dens_beta = {4.63822910e-02 / 1000, 1.86080048e-01 / 1000, 2.48667176e-02 / 1000, 4.81080852e-03 / 1000};
+        d.dens_gamma = {5.01594516e00 * 1000, 2.28429809e01 * 1000, 4.27957829e00 * 1000, 1.56291673e-01 * 1000};
+    }
+    return d;
+}
+
 } // namespace dynamics
 
 namespace
@@ -281,8 +314,13 @@ void sim::finalise_ctor(options o)
     m_coll_whitelist = std::move(o.coll_whitelist);
     m_conj_whitelist = std::move(o.conj_whitelist);
 
-    if (o.dyn.kind != dynamics::dyn_t::kepler) {
-        throw std::invalid_argument("Unknown built-in dynamics kind " + std::to_string(static_cast<int>(o.dyn.kind)));
+    if (o.dyn.kind != dynamics::dyn_t::kepler && o.dyn.kind != dynamics::dyn_t::j2
+        && o.dyn.kind != (dynamics::dyn_t::j2 | dynamics::dyn_t::drag)) {
+        throw std::invalid_argument("Unknown built-in dynamics kind " + std::to_string(o.dyn.kind));
+    }
+    if (!std::isfinite(o.dyn.mu) || o.dyn.mu <= 0) {
+        throw std::invalid_argument("The mu parameter of the dynamics must be finite and positive, but it is "
+                                    + fmt_d(o.dyn.mu) + " instead");
     }
     m_data->dyn = o.dyn;
     m_npars = o.dyn.npars;
@@ -735,10 +773,26 @@ outcome sim::step()
     d.chk(csc_activity_flags(ctx, n, d_state, m_min_coll_radius, with_conj ? 1 : 0, cwl.data(), cwl.size(), jwl.data(),
                              jwl.size(), d_active));
 
+    // Runtime parameters (host vector is authoritative, like the state).
+    double *d_pars = nullptr;
+    if (m_npars != 0u) {
+        d_pars = d.buf<double>("pars", static_cast<std::size_t>(n) * m_npars);
+        d.chk(csc_memcpy_h2d(ctx, d_pars, m_pars->data(), static_cast<std::size_t>(n) * m_npars * sizeof(double)));
+    }
+
     csc_prop_cfg cfg{};
-    cfg.dyn_kind = CSC_DYN_KEPLER;
+    cfg.dyn_kind = d.dyn.kind;
     cfg.order = d.order;
     cfg.mu = d.dyn.mu;
+    cfg.J2 = d.dyn.J2;
+    cfg.Re = d.dyn.Re;
+    for (int k = 0; k < 4; ++k) {
+        cfg.dens_alpha[k] = d.dyn.dens_alpha[k];
+        cfg.dens_beta[k] = d.dyn.dens_beta[k];
+        cfg.dens_gamma[k] = d.dyn.dens_gamma[k];
+    }
+    cfg.d_pars = d_pars;
+    cfg.npars = m_npars;
     cfg.rhofac = std::exp(-0.7 / (d.order - 1)) / (std::exp(1.) * std::exp(1.));
     cfg.init_time_hi = d.time.hi;
     cfg.init_time_lo = d.time.lo;

@@ -34,7 +34,12 @@
 namespace csc
 {
 
-enum : int { DYN_KEPLER = 0 };
+// Dynamics: Kepler plus a bit mask of perturbations (cascade.py/dynamics/_simple_earth.py).
+enum : int {
+    DYN_KEPLER = 0,
+    DYN_J2 = 1,   // :169-178
+    DYN_DRAG = 2, // :365-387 with the exponential density fit :16-46; par[0] = BSTAR
+};
 
 enum : int {
     ST_TIME_LIMIT = 0,
@@ -55,6 +60,11 @@ struct prop_params {
     double conj_thresh;
     double mu;
     double rhofac;
+    // Perturbations: kj2 = 1.5 J2 mu Re^2; density fit rho(h) = sum alpha_k exp(-(h - gamma_k) beta_k).
+    double kj2, Re;
+    double dens_alpha[4], dens_beta[4], dens_gamma[4];
+    const double *pars; // [N][npars] runtime parameters (BSTAR = pars[i * npars]); null if npars == 0
+    std::uint32_t npars;
     // Terminal events (src/sim_basic.cpp:509-578): g = (kx x^2 + ky y^2) + kz z^2 - c0.
     int has_exit;
     double exit_c0;
@@ -127,14 +137,47 @@ struct tc_regs {
     double x[P + 1], y[P + 1], z[P + 1], vx[P + 1], vy[P + 1], vz[P + 1], r[P + 1];
 };
 
-template <int P, int N>
-struct kepler_order {
-    static CSC_DEV void run(tc_regs<P> &t, double *u, double *w, double mu, double inv_u0, double inv_r0)
+// Per-step constants of the Taylor recurrences.
+struct dyn_consts {
+    double mu, inv_u0, inv_r0;
+    double kj2;                                    // J2
+    double Re, cdrag, inv_2s0, inv_2mv0;           // drag: cdrag = BSTAR / (0.1570 / Re)
+    double alpha[4], mbeta[4], gamma[4];           // density fit (mbeta = -beta)
+};
+
+// Auxiliary series (orders 0..P-1); the members of perturbations that are not selected are
+// never touched and cost nothing.
+template <int P>
+struct dyn_aux {
+    double u[P], w[P];
+    double w2[P], w5[P], z2[P], q[P], fxy[P], fz[P];                // J2
+    double sq[P], ek[4][P], dens[P], vv[P], mv[P], fd[P];           // drag
+};
+
+template <int N>
+CSC_DEV double conv_shift0(const double *a, const double *b, double b0)
+{
+    // sum_{j<=N} a[j] * (N - j == 0 ? b0 : b[N - j])
+    double acc = 0;
+#pragma unroll
+    for (int j = 0; j <= N; ++j) {
+        acc = fma(a[j], (N - j == 0) ? b0 : b[N - j], acc);
+    }
+    return acc;
+}
+
+// Order N of the recurrences: coefficients N of the auxiliary series, N + 1 of the state.
+// Same operations in the same order as oracle/orc.hpp::compute_tcs.
+template <int P, int N, int DYN>
+struct dyn_order {
+    static CSC_DEV void run(tc_regs<P> &t, dyn_aux<P> &a, dyn_consts &k)
     {
+        double *u = a.u, *w = a.w;
         // u = x^2 + y^2 + z^2
         u[N] = (conv_sq<N>(t.x) + conv_sq<N>(t.y)) + conv_sq<N>(t.z);
         // w = u^(-3/2): w[n] = (1 / (n u0)) sum_{j<n} (n alpha - j (alpha + 1)) u[n-j] w[j]
         if constexpr (N == 0) {
+            k.inv_u0 = 1. / u[0];
             w[0] = 1. / (u[0] * sqrt(u[0]));
         } else {
             double acc = 0;
@@ -143,11 +186,78 @@ struct kepler_order {
                 const double cf = 0.5 * static_cast<double>(j) - 1.5 * static_cast<double>(N);
                 acc = fma(cf * u[N - j], w[j], acc);
             }
-            w[N] = (acc * inv_u0) * (1. / static_cast<double>(N));
+            w[N] = (acc * k.inv_u0) * (1. / static_cast<double>(N));
         }
-        const double ax = -mu * conv<N>(t.x, w);
-        const double ay = -mu * conv<N>(t.y, w);
-        const double az = -mu * conv<N>(t.z, w);
+        double ax = -k.mu * conv<N>(t.x, w);
+        double ay = -k.mu * conv<N>(t.y, w);
+        double az = -k.mu * conv<N>(t.z, w);
+        if constexpr ((DYN & DYN_J2) != 0) {
+            // ax += kj2 x / r^5 (5 z^2 / r^2 - 1), ay likewise, az += kj2 z / r^5 (5 z^2 / r^2 - 3).
+            if constexpr (N == 0) {
+                a.w2[0] = k.inv_u0;
+            } else {
+                double acc = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    acc = fma(u[N - j], a.w2[j], acc);
+                }
+                a.w2[N] = -(acc * k.inv_u0);
+            }
+            a.w5[N] = conv<N>(w, a.w2);
+            a.z2[N] = conv_sq<N>(t.z);
+            a.q[N] = 5. * conv<N>(a.z2, a.w2);
+            a.fxy[N] = k.kj2 * conv_shift0<N>(a.w5, a.q, a.q[0] - 1.);
+            a.fz[N] = k.kj2 * conv_shift0<N>(a.w5, a.q, a.q[0] - 3.);
+            ax += conv<N>(t.x, a.fxy);
+            ay += conv<N>(t.y, a.fxy);
+            az += conv<N>(t.z, a.fz);
+        }
+        if constexpr ((DYN & DYN_DRAG) != 0) {
+            // a -= (rho(r - Re) / ref_density) BSTAR |v| v.
+            if constexpr (N == 0) {
+                a.sq[0] = sqrt(u[0]);
+                k.inv_2s0 = 1. / (2. * a.sq[0]);
+            } else {
+                double acc = u[N];
+#pragma unroll
+                for (int j = 1; j < N; ++j) {
+                    acc = fma(-a.sq[j], a.sq[N - j], acc);
+                }
+                a.sq[N] = acc * k.inv_2s0;
+            }
+            double dsum = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (N == 0) {
+                    a.ek[e][0] = det_exp(k.mbeta[e] * ((a.sq[0] - k.Re) - k.gamma[e]));
+                } else {
+                    double acc = 0;
+#pragma unroll
+                    for (int j = 1; j <= N; ++j) {
+                        acc = fma((static_cast<double>(j) * k.mbeta[e]) * a.sq[j], a.ek[e][N - j], acc);
+                    }
+                    a.ek[e][N] = acc * (1. / static_cast<double>(N == 0 ? 1 : N));
+                }
+                dsum = fma(k.alpha[e], a.ek[e][N], dsum);
+            }
+            a.dens[N] = dsum;
+            a.vv[N] = (conv_sq<N>(t.vx) + conv_sq<N>(t.vy)) + conv_sq<N>(t.vz);
+            if constexpr (N == 0) {
+                a.mv[0] = sqrt(a.vv[0]);
+                k.inv_2mv0 = 1. / (2. * a.mv[0]);
+            } else {
+                double acc = a.vv[N];
+#pragma unroll
+                for (int j = 1; j < N; ++j) {
+                    acc = fma(-a.mv[j], a.mv[N - j], acc);
+                }
+                a.mv[N] = acc * k.inv_2mv0;
+            }
+            a.fd[N] = conv<N>(a.dens, a.mv) * k.cdrag;
+            ax -= conv<N>(a.fd, t.vx);
+            ay -= conv<N>(a.fd, t.vy);
+            az -= conv<N>(a.fd, t.vz);
+        }
         // r' = (x vx + y vy + z vz) / r
         const double s = (conv<N>(t.x, t.vx) + conv<N>(t.y, t.vy)) + conv<N>(t.z, t.vz);
         double acc = s;
@@ -156,7 +266,7 @@ struct kepler_order {
             const double qr = static_cast<double>(N - j + 1) * t.r[N - j + 1];
             acc = fma(-t.r[j], qr, acc);
         }
-        const double qn = acc * inv_r0;
+        const double qn = acc * k.inv_r0;
         constexpr double f = 1. / static_cast<double>(N + 1);
         t.x[N + 1] = t.vx[N] * f;
         t.y[N + 1] = t.vy[N] * f;
@@ -166,22 +276,33 @@ struct kepler_order {
         t.vz[N + 1] = az * f;
         t.r[N + 1] = qn * f;
         if constexpr (N + 1 < P) {
-            kepler_order<P, N + 1>::run(t, u, w, mu, inv_u0, inv_r0);
+            dyn_order<P, N + 1, DYN>::run(t, a, k);
         }
     }
 };
 
 // Normalised Taylor coefficients (orders 1..P) of the 7 state variables; order 0 must be
-// set by the caller. Kepler RHS src/sim_dynamics.cpp:36-41, r equation src/sim_basic.cpp:469.
-template <int P>
-CSC_DEV void compute_tcs_kepler(tc_regs<P> &t, double mu)
+// set by the caller. Kepler RHS src/sim_dynamics.cpp:36-41, r equation src/sim_basic.cpp:469,
+// J2 and drag cascade.py/dynamics/_simple_earth.py:169-178, 365-387.
+template <int P, int DYN>
+CSC_DEV void compute_tcs(tc_regs<P> &t, const prop_params &prm, double bstar)
 {
-    double u[P], w[P];
-    // NOTE: u[0] is recomputed inside order 0; the reciprocals only need it.
-    const double u0 = (t.x[0] * t.x[0] + t.y[0] * t.y[0]) + t.z[0] * t.z[0];
-    const double inv_u0 = 1. / u0;
-    const double inv_r0 = 1. / t.r[0];
-    kepler_order<P, 0>::run(t, u, w, mu, inv_u0, inv_r0);
+    dyn_aux<P> a;
+    dyn_consts k;
+    k.mu = prm.mu;
+    k.inv_u0 = 0.;
+    k.inv_r0 = 1. / t.r[0];
+    k.kj2 = prm.kj2;
+    k.Re = prm.Re;
+    k.cdrag = bstar / (0.1570 / prm.Re);
+    k.inv_2s0 = k.inv_2mv0 = 0.;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        k.alpha[e] = prm.dens_alpha[e];
+        k.mbeta[e] = -prm.dens_beta[e];
+        k.gamma[e] = prm.dens_gamma[e];
+    }
+    dyn_order<P, 0, DYN>::run(t, a, k);
 }
 
 template <int P>
@@ -229,7 +350,7 @@ CSC_DEV_NOINLINE double event_first_root(const double *g_in, double h, int direc
     return best;
 }
 
-template <int P, bool EVENTS, bool STORE>
+template <int P, bool EVENTS, bool STORE, int DYN>
 __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
 {
     const std::uint32_t lane_k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,6 +373,10 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
     t.vy[0] = sp[4];
     t.vz[0] = sp[5];
     const double p_radius = sp[6];
+    double bstar = 0.;
+    if constexpr ((DYN & DYN_DRAG) != 0) {
+        bstar = prm.pars[static_cast<std::size_t>(i) * prm.npars];
+    }
     // src/sim_propagate.cpp:160
     t.r[0] = sqrt(t.x[0] * t.x[0] + t.y[0] * t.y[0] + t.z[0] * t.z[0]);
 
@@ -334,7 +459,7 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
         const dfl rem = df_sub(t_end, tm);
         const double max_dt = rem.hi > 0. ? rem.hi : 0.;
 
-        compute_tcs_kepler<P>(t, prm.mu);
+        compute_tcs<P, DYN>(t, prm, bstar);
 
         // Jorba-Zou step size (heyoka, EXTERNAL).
         double m0 = 0, mo = 0, mom1 = 0;

@@ -15,3 +15,12 @@ def kepler(mu: float = 1.0):
     if not math.isfinite(mu) or mu <= 0:
         raise ValueError("The mu parameter for Keplerian dynamics must be finite and positive, but it is {} instead".format(mu))
     return core._kepler(float(mu))
+
+
+def simple_earth(J2=True, J3=False, J4=False, C22S22=True, sun=False, moon=False, SRP=False, drag=True, thermonets=False):
+    """Perturbed dynamics around the Earth in SI units: signature and defaults of the reference's
+    ``cascade.dynamics.simple_earth`` (cascade.py/dynamics/_simple_earth.py:86-96). Built so
+    far: ``J2`` and ``drag`` (exponential density fit; pass every object's BSTAR as its first
+    simulation parameter, ``pars``). Any other term raises ``ValueError`` -- note that the
+    reference switches ``C22S22`` on by default, so it has to be turned off explicitly here."""
+    return core._simple_earth(J2, J3, J4, C22S22, sun, moon, SRP, drag, thermonets)

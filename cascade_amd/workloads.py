@@ -58,3 +58,33 @@ def random_leo_pop_kep(nparts=17378, seed=42):
     st[:, 3:6] = v
     st[:, 6] = size
     return st
+
+
+def leo_si_population(n, seed=42, with_bstar=True):
+    """Synthetic LEO population in SI units for the perturbed dynamics (J2 / drag): near-circular
+    orbits, altitude 250-1200 km, all inclinations, sizes 0.1-5 m, BSTAR log-uniform in
+    [1e-5, 1e-3] (SI form of simple_earth: acceleration = rho / rho_ref * BSTAR * |v| v).
+    Returns (state [n, 7], pars [n, 1])."""
+    rng = np.random.default_rng(seed)
+    GM, Re = 3.986004407799724e14, 6378136.3
+    a = Re + rng.uniform(250e3, 1200e3, n)
+    e = rng.uniform(0.0, 0.01, n)
+    inc = np.arccos(rng.uniform(-1.0, 1.0, n))
+    Om, om, nu = (rng.uniform(0, 2 * np.pi, n) for _ in range(3))
+    p = a * (1 - e * e)
+    r = p / (1 + e * np.cos(nu))
+    h = np.sqrt(GM * p)
+    cO, sO, ci, si = np.cos(Om), np.sin(Om), np.cos(inc), np.sin(inc)
+    cu, su = np.cos(om + nu), np.sin(om + nu)
+    x = r * (cO * cu - sO * su * ci)
+    y = r * (sO * cu + cO * su * ci)
+    z = r * (si * su)
+    vr = h * e * np.sin(nu) / p
+    vt = h / r
+    vx = vr * x / r - vt * (cO * su + sO * cu * ci)
+    vy = vr * y / r - vt * (sO * su - cO * cu * ci)
+    vz = vr * z / r + vt * si * cu
+    size = rng.uniform(0.1, 5.0, n)
+    st = np.stack([x, y, z, vx, vy, vz, size], axis=1)
+    pars = np.exp(rng.uniform(np.log(1e-5), np.log(1e-3), n)).reshape(n, 1) if with_bstar else np.zeros((n, 0))
+    return np.ascontiguousarray(st), np.ascontiguousarray(pars)

@@ -49,19 +49,34 @@ namespace dynamics
 // Built-in dynamics descriptor (replaces std::vector<std::pair<heyoka::expression,
 // heyoka::expression>>, sim.hpp:213-222).
 struct dyn_t {
-    enum kind_t : int { kepler = 0 };
-    kind_t kind = kepler;
+    // Kepler plus a bit mask of perturbations.
+    enum kind_t : int { kepler = 0, j2 = 1, drag = 2 };
+    int kind = kepler;
     double mu = 1.;
-    std::uint32_t npars = 0;
+    std::uint32_t npars = 0; // runtime parameters per particle (drag: 1 = BSTAR)
+    double J2 = 0.;
+    double Re = 1.;
+    // rho(h) = sum_k alpha_k exp(-(h - gamma_k) beta_k), h = r - Re (SI units)
+    std::array<double, 4> dens_alpha = {}, dens_beta = {}, dens_gamma = {};
 
     friend bool operator==(const dyn_t &a, const dyn_t &b)
     {
-        return a.kind == b.kind && a.mu == b.mu && a.npars == b.npars;
+        return a.kind == b.kind && a.mu == b.mu && a.npars == b.npars && a.J2 == b.J2 && a.Re == b.Re
+               && a.dens_alpha == b.dens_alpha && a.dens_beta == b.dens_beta && a.dens_gamma == b.dens_gamma;
     }
 };
 
 // src/sim_dynamics.cpp:25-42
 dyn_t kepler(double mu = 1.);
+
+// Perturbed dynamics around the Earth in SI units, same signature and defaults as the
+// reference's cascade.dynamics.simple_earth (cascade.py/dynamics/_simple_earth.py:86-96). Built
+// so far: J2 (:169-178) and drag with the exponential density fit (:365-387, :16-46; the BSTAR
+// coefficient of every object is its first runtime parameter, kw::pars). Asking for a term
+// that is not built (J3, J4, C22S22 -- on by default in the reference --, sun, moon, SRP,
+// thermonets) throws std::invalid_argument.
+dyn_t simple_earth(bool J2 = true, bool J3 = false, bool J4 = false, bool C22S22 = true, bool sun = false,
+                   bool moon = false, bool SRP = false, bool drag = true, bool thermonets = false);
 
 } // namespace dynamics
 

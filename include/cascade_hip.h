@@ -40,8 +40,11 @@ typedef enum csc_status {
     CSC_ERR_OVERFLOW = -8        /* an output buffer was too small (sizes returned) */
 } csc_status;
 
-/* Built-in dynamics (replace the heyoka expression vector of kw::dyn, sim.hpp:213-222). */
-enum { CSC_DYN_KEPLER = 0 }; /* src/sim_dynamics.cpp:25-42 */
+/* Built-in dynamics (replace the heyoka expression vector of kw::dyn, sim.hpp:213-222): Kepler
+ * (src/sim_dynamics.cpp:25-42) plus a bit mask of the perturbations of simple_earth()
+ * (cascade.py/dynamics/_simple_earth.py): J2 (:169-178) and atmospheric drag with the 4-term
+ * exponential density fit (:365-387, :16-46; runtime parameter 0 of a particle = BSTAR). */
+enum { CSC_DYN_KEPLER = 0, CSC_DYN_J2 = 1, CSC_DYN_DRAG = 2 };
 
 /* Integrator + event configuration of one superstep. Replaces what sim::finalise_ctor bakes
  * into the heyoka integrators (src/sim_basic.cpp:461-578). */
@@ -63,6 +66,14 @@ typedef struct csc_prop_cfg {
     int32_t has_reentry;   /* event index has_exit, direction - */
     double reentry_k[3];   /* {1,1,1} for a sphere; {(bc)^2, (ac)^2, (ab)^2} for an ellipsoid */
     double reentry_c0;     /* R^2 or (abc)^2 */
+    /* perturbations (used when the matching bit of dyn_kind is set) */
+    double J2;             /* 0.1082635854e-2 for the Earth */
+    double Re;             /* equatorial radius (J2) / radius of the spherical Earth (drag altitude) */
+    double dens_alpha[4];  /* rho(h) = sum_k alpha_k exp(-(h - gamma_k) beta_k), h = r - Re */
+    double dens_beta[4];
+    double dens_gamma[4];
+    const double *d_pars;  /* DEVICE [n][npars] runtime parameters; BSTAR = d_pars[i * npars] */
+    uint32_t npars;
 } csc_prop_cfg;
 
 /* Per-particle status written by csc_propagate: low byte 0 time limit / 1 stopping terminal

@@ -165,9 +165,11 @@ inline ival operator*(ival a, ival b)
 // Dynamics descriptors (replace the heyoka expression vector of kw::dyn,
 // include/cascade/sim.hpp:213-222).
 // ---------------------------------------------------------------------------
+// kind is a bit mask: Kepler plus the selected perturbations of simple_earth().
 enum dyn_kind : int {
     DYN_KEPLER = 0,    // src/sim_dynamics.cpp:25-42
-    DYN_KEPLER_J2 = 1, // cascade.py/dynamics/_simple_earth.py:169-178
+    DYN_KEPLER_J2 = 1, // bit 0: J2, cascade.py/dynamics/_simple_earth.py:169-178
+    DYN_DRAG = 2,      // bit 1: drag with the 4-term exponential density fit, :365-387 and :16-46
 };
 
 struct dynamics {
@@ -175,9 +177,14 @@ struct dynamics {
     double mu = 1.;
     double J2 = 0.;
     double Re = 1.;
+    // Density fit rho(h) = sum_k alpha_k exp(-(h - gamma_k) beta_k), h = r - Re (the fitted
+    // constants of _simple_earth.py:24-39 / benchmark/data/best_fit_density.txt, SI units).
+    double dens_alpha[4] = {1.01709935e-06, 7.86443375e-01, 7.50341883e-09, 8.63934252e-14};
+    double dens_beta[4] = {4.63822910e-02 / 1000, 1.86080048e-01 / 1000, 2.48667176e-02 / 1000, 4.81080852e-03 / 1000};
+    double dens_gamma[4] = {5.01594516e00 * 1000, 2.28429809e01 * 1000, 4.27957829e00 * 1000, 1.56291673e-01 * 1000};
     std::uint32_t npars() const
     {
-        return 0;
+        return (kind & DYN_DRAG) ? 1u : 0u; // par[0] = BSTAR (:367)
     }
 };
 
@@ -777,7 +784,8 @@ struct taylor_work {
     // tc[c][o], c in x,y,z,vx,vy,vz,r.
     std::vector<double> tc;
     std::vector<double> u, w, g, inv;
-    std::vector<double> aux[8];
+    std::vector<double> aux[20];
+    double par0 = 0; // first runtime parameter of the particle being integrated (BSTAR)
     rf_scratch rfs;
     rf_stats rf_st;
     void prepare(std::uint32_t p)
@@ -831,6 +839,8 @@ inline double conv_sq(const double *a, std::uint32_t n)
     return acc;
 }
 
+inline double det_exp(double t);
+
 // Normalised Taylor coefficients of the 7 state variables at the current state
 // (heyoka AD recurrences, EXTERNAL). Kepler RHS:
 // src/sim_dynamics.cpp:36-41; r equation: src/sim_basic.cpp:469.
@@ -853,7 +863,15 @@ inline void compute_tcs(const taylor_cfg &cfg, taylor_work &wk, const double st[
     const double inv_r0 = 1. / r[0];
 
     // J2 auxiliaries (kind 1): see compute below.
-    const bool j2 = cfg.dyn.kind == DYN_KEPLER_J2;
+    const bool j2 = (cfg.dyn.kind & DYN_KEPLER_J2) != 0;
+    const bool drag = (cfg.dyn.kind & DYN_DRAG) != 0;
+    // Drag auxiliaries: s = sqrt(u), e_k = exp(-beta_k (s - Re - gamma_k)), dens = sum alpha_k e_k,
+    // vv = |v|^2, mv = sqrt(vv), fd = (dens * mv) * (BSTAR / ref_density).
+    double *sq = wk.aux[6].data(), *dens = wk.aux[7].data(), *vv = wk.aux[8].data(), *mv = wk.aux[9].data(),
+           *fd = wk.aux[10].data();
+    double *ek[4] = {wk.aux[11].data(), wk.aux[12].data(), wk.aux[13].data(), wk.aux[14].data()};
+    const double cdrag = wk.par0 / (0.1570 / cfg.dyn.Re);
+    double inv_2s0 = 0, inv_2mv0 = 0;
     double *w5 = wk.aux[0].data(), *z2 = wk.aux[1].data(), *q = wk.aux[2].data(), *fxy = wk.aux[3].data(),
            *fz = wk.aux[4].data(), *w2 = wk.aux[5].data();
     const double kj2 = 1.5 * cfg.dyn.J2 * cfg.dyn.mu * cfg.dyn.Re * cfg.dyn.Re;
@@ -911,6 +929,53 @@ inline void compute_tcs(const taylor_cfg &cfg, taylor_work &wk, const double st[
             ax += conv(x, fxy, n);
             ay += conv(y, fxy, n);
             az += conv(z, fz, n);
+        }
+        if (drag) {
+            // Drag acceleration (cascade.py/dynamics/_simple_earth.py:365-387), spherical Earth:
+            //   a -= (rho(r - Re) / ref_density) BSTAR |v| v,   ref_density = 0.1570 / Re.
+            // sqrt series: c = sqrt(a): c[n] = (a[n] - sum_{j=1}^{n-1} c[j] c[n-j]) / (2 c[0]).
+            if (n == 0u) {
+                sq[0] = std::sqrt(u[0]);
+                inv_2s0 = 1. / (2. * sq[0]);
+            } else {
+                double acc = u[n];
+                for (std::uint32_t j = 1; j < n; ++j) {
+                    acc = std::fma(-sq[j], sq[n - j], acc);
+                }
+                sq[n] = acc * inv_2s0;
+            }
+            double dsum = 0;
+            for (int k = 0; k < 4; ++k) {
+                // e = exp(g), g[0] = -beta (s[0] - Re - gamma), g[m] = -beta s[m]:
+                // e[n] = (1 / n) sum_{j=1}^{n} j g[j] e[n-j].
+                const double mb = -cfg.dyn.dens_beta[k];
+                if (n == 0u) {
+                    ek[k][0] = det_exp(mb * ((sq[0] - cfg.dyn.Re) - cfg.dyn.dens_gamma[k]));
+                } else {
+                    double acc = 0;
+                    for (std::uint32_t j = 1; j <= n; ++j) {
+                        acc = std::fma((static_cast<double>(j) * mb) * sq[j], ek[k][n - j], acc);
+                    }
+                    ek[k][n] = acc * inv[n];
+                }
+                dsum = std::fma(cfg.dyn.dens_alpha[k], ek[k][n], dsum);
+            }
+            dens[n] = dsum;
+            vv[n] = (conv_sq(vx, n) + conv_sq(vy, n)) + conv_sq(vz, n);
+            if (n == 0u) {
+                mv[0] = std::sqrt(vv[0]);
+                inv_2mv0 = 1. / (2. * mv[0]);
+            } else {
+                double acc = vv[n];
+                for (std::uint32_t j = 1; j < n; ++j) {
+                    acc = std::fma(-mv[j], mv[n - j], acc);
+                }
+                mv[n] = acc * inv_2mv0;
+            }
+            fd[n] = conv(dens, mv, n) * cdrag;
+            ax -= conv(fd, vx, n);
+            ay -= conv(fd, vy, n);
+            az -= conv(fd, vz, n);
         }
         // r' = (x vx + y vy + z vz) / r, with q_r[m] = (m + 1) r[m + 1].
         const double s = (conv(x, vx, n) + conv(y, vy, n)) + conv(z, vz, n);

@@ -221,6 +221,25 @@ void *orc_sim_new(const double *state, std::uint64_t nparts, double ct, std::uin
     return ret;
 }
 
+// Runtime parameters [nparts][npars] (BSTAR per particle when drag is on; cascade.py/dynamics/
+// _simple_earth.py:367) and, optionally, the 12 constants of the density fit (alpha, beta per
+// metre, gamma in metres).
+int orc_sim_set_pars(void *h, const double *pars, std::uint64_t n, const double *dens12)
+{
+    return guarded([&]() {
+        auto &p = S(h)->prm;
+        p.pars.assign(pars, pars + n);
+        if (dens12) {
+            for (int k = 0; k < 4; ++k) {
+                p.tcfg.dyn.dens_alpha[k] = dens12[k];
+                p.tcfg.dyn.dens_beta[k] = dens12[4 + k];
+                p.tcfg.dyn.dens_gamma[k] = dens12[8 + k];
+            }
+        }
+        return 0;
+    });
+}
+
 void orc_sim_free(void *h)
 {
     delete S(h);

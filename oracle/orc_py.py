@@ -94,6 +94,8 @@ def lib():
         L.orc_broad_phase.argtypes = [u64, vp, vp, vp, vp, vp, vp, vp, u64]
         L.orc_broad_phase_brute.restype = C.c_int64
         L.orc_broad_phase_brute.argtypes = [u64, vp, vp, vp, vp, vp, u64]
+        L.orc_sim_set_pars.restype = i32
+        L.orc_sim_set_pars.argtypes = [vp, vp, u64, vp]
         L.orc_sim_new.restype = vp
         L.orc_sim_new.argtypes = [vp, u64, dbl, u32, dbl, dbl, dbl, i32, dbl, dbl, dbl, dbl, i32, vp]
         L.orc_sim_free.argtypes = [vp]
@@ -197,6 +199,8 @@ class Sim:
         reentry_radius=0.0,
         coll_whitelist=(),
         conj_whitelist=(),
+        pars=None,
+        dens=None,
     ):
         L = lib()
         st = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(-1, 7))
@@ -212,6 +216,12 @@ class Sim:
         if not self._h:
             raise OracleError(L.orc_last_error().decode())
         self._L = L
+        if pars is not None:
+            # dyn_kind bit 1 (drag): pars[:, 0] = BSTAR; dens = the 12 density-fit constants or None
+            pr = np.ascontiguousarray(np.asarray(pars, dtype=np.float64).reshape(-1))
+            d12 = None if dens is None else np.ascontiguousarray(np.asarray(dens, dtype=np.float64).reshape(12))
+            if L.orc_sim_set_pars(self._h, _p(pr), pr.size, None if d12 is None else _p(d12)) != 0:
+                raise OracleError(L.orc_last_error().decode())
         self.set_whitelists(coll_whitelist, conj_whitelist)
 
     def __del__(self):

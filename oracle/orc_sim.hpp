@@ -26,6 +26,7 @@ struct sim_params {
     double conj_thresh = 0;
     double min_coll_radius = 0;
     taylor_cfg tcfg;
+    std::vector<double> pars; // [N][npars] runtime parameters (BSTAR when drag is on), zero if empty
 };
 
 struct stage_times {
@@ -216,6 +217,7 @@ public:
                                                           && (coll_wl_empty || m_coll_whitelist.count(pidx) == 1u));
                     conj_active[pidx]
                         = static_cast<char>(with_conj && (conj_wl_empty || m_conj_whitelist.count(pidx) == 1u));
+                    wk.par0 = (prm.tcfg.dyn.npars() != 0u && pidx < prm.pars.size()) ? prm.pars[pidx] : 0.;
                     const auto res = propagate_particle(prm.tcfg, wk, &m_state[pidx * 7u], init_time, delta_t0,
                                                         s_data[pidx], &final_state[pidx * 6u]);
                     if (res.status == 2) {

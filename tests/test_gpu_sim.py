@@ -247,3 +247,48 @@ def test_prefilter_changes_nothing(n, n_par_ct, conj, scale):
             assert a.last_np_candidates < 0.5 * a.last_bp_pairs, (a.last_np_candidates, a.last_bp_pairs)
     if scale > 1 or conj > 0:
         assert n_events > 0, "the test population should produce events"
+
+
+@pytest.mark.parametrize("kind,n,n_par_ct,conj", [("j2", 3000, 3, 0.0), ("j2drag", 3000, 4, 5000.0), ("j2drag", 1500, 1, 0.0)])
+@pytest.mark.gpu
+def test_perturbed_dynamics_vs_oracle(orc, kind, n, n_par_ct, conj):
+    """J2 and J2 + drag (simple_earth, SI units): whole-step parity with the CPU oracle -- same
+    outcomes, pair counts and conjunction sets, states within 1e-9 relative."""
+    from cascade_amd import dynamics, sim
+    from cascade_amd.workloads import leo_si_population
+
+    st, pars = leo_si_population(n, seed=3)
+    st[:, 6] *= 50.0  # bigger objects: a few collisions
+    drag = kind == "j2drag"
+    dyn = dynamics.simple_earth(J2=True, C22S22=False, drag=drag)
+    ct = 185.5663
+    rr = 6378136.3 + 150e3
+    g = sim(st.copy(), ct, dyn=dyn, pars=pars if drag else None, n_par_ct=n_par_ct, conj_thresh=conj, reentry_radius=rr)
+    o = orc.Sim(st.copy(), ct, n_par_ct=n_par_ct, conj_thresh=conj, dyn_kind=3 if drag else 1, mu=dyn.mu, J2=dyn.J2, Re=dyn.Re, reentry_radius=rr, pars=pars if drag else None)
+    assert g.npars == (1 if drag else 0)
+    for _ in range(4):
+        og, oo = g.step(), o.step()
+        assert og.name == oo
+        assert _ii(g.interrupt_info) == o.interrupt_info
+        assert abs(g.time - o.time) <= RTOL * max(1.0, abs(o.time))
+        assert np.all(np.abs(g.state - o.state) <= RTOL * np.maximum(1.0, np.abs(o.state)))
+        assert g.last_bp_pairs == int(o.stage_times()["n_bp_pairs"])
+    cg, co = g.conjunctions, o.conjunctions
+    assert len(cg) == len(co)
+    if len(co):
+        assert np.array_equal(cg["i"], co["i"]) and np.array_equal(cg["j"], co["j"])
+        assert np.all(np.abs(cg["time"] - co["time"]) <= RTOL * np.maximum(1.0, np.abs(co["time"])))
+
+
+@pytest.mark.gpu
+def test_drag_decays_and_reenters():
+    """A low object with a large BSTAR loses altitude under drag and triggers the reentry event."""
+    from cascade_amd import dynamics, outcome, sim
+
+    Re, GM = 6378136.3, 3.986004407799724e14
+    r0 = Re + 180e3
+    st = np.array([[r0, 0.0, 0.0, 0.0, np.sqrt(GM / r0), 0.0, 1.0]])
+    s = sim(st, 185.5663, dyn=dynamics.simple_earth(C22S22=False), pars=np.array([[5e-2]]), n_par_ct=8, reentry_radius=Re + 150e3)
+    oc = s.propagate_until(86400.0 * 2)
+    assert oc == outcome.reentry and s.interrupt_info == 0
+    assert abs(np.linalg.norm(s.state[0, :3]) - (Re + 150e3)) < 1e-6
