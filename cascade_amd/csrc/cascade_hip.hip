@@ -71,6 +71,7 @@ struct csc_ctx {
     };
     std::map<std::string, ktimer> kt;
     bool profiling = false;
+    std::vector<csc_tape_op> tape_host; // the tape currently in the "tape_ops" buffer
     void kt_begin(const char *name)
     {
         if (!profiling) {
@@ -338,6 +339,12 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
     }
     p.pars = cfg->d_pars;
     p.npars = cfg->npars;
+    p.tape = nullptr;
+    p.tape_nops = p.tape_nslots = 0;
+    p.tape_ws = nullptr;
+    for (int i = 0; i < 7; ++i) {
+        p.tape_rhs[i] = cfg->tape_rhs[i];
+    }
     return p;
 }
 
@@ -357,6 +364,9 @@ void launch_propagate(int dyn, bool events, dim3 grid, dim3 block, hipStream_t s
         case 1:
             CSC_PROP_CASE(1)
             break;
+        case csc::DYN_TAPE:
+            CSC_PROP_CASE(csc::DYN_TAPE)
+            break;
         default:
             CSC_PROP_CASE(3)
             break;
@@ -373,9 +383,34 @@ int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
         ctx->err = "only Taylor order 20 (tol = DBL_EPSILON) is built";
         return CSC_ERR_UNSUPPORTED;
     }
-    if (cfg->dyn_kind != CSC_DYN_KEPLER && cfg->dyn_kind != CSC_DYN_J2 && cfg->dyn_kind != (CSC_DYN_J2 | CSC_DYN_DRAG)) {
-        ctx->err = "unknown dynamics kind (built: Kepler, Kepler + J2, Kepler + J2 + drag)";
+    if (cfg->dyn_kind != CSC_DYN_KEPLER && cfg->dyn_kind != CSC_DYN_J2 && cfg->dyn_kind != (CSC_DYN_J2 | CSC_DYN_DRAG)
+        && cfg->dyn_kind != CSC_DYN_TAPE) {
+        ctx->err = "unknown dynamics kind (built: Kepler, Kepler + J2, Kepler + J2 + drag, tape)";
         return CSC_ERR_UNSUPPORTED;
+    }
+    if (cfg->dyn_kind == CSC_DYN_TAPE) {
+        // Every operation defines a new slot from earlier ones; anything else would read
+        // coefficients that do not exist yet (or memory outside the workspace).
+        if (cfg->tape == nullptr || cfg->tape_nops == 0u || cfg->tape_nslots < 8u || cfg->tape_nslots > (1u << 16)) {
+            return ctx->invalid("tape dynamics without a tape");
+        }
+        for (uint32_t k = 0; k < cfg->tape_nops; ++k) {
+            const csc_tape_op &o = cfg->tape[k];
+            const uint32_t last = static_cast<uint32_t>(o.dst) + (o.op == CSC_TP_SINCOS ? 1u : 0u);
+            if (o.op < CSC_TP_ADD || o.op > CSC_TP_CONST || o.dst < 7 || last >= cfg->tape_nslots || o.a < 0 || o.a >= o.dst
+                || o.b >= o.dst || (o.b <= -2 && static_cast<uint32_t>(-2 - o.b) >= cfg->npars)
+                || ((o.op == CSC_TP_RSUB || o.op == CSC_TP_RDIV || o.op == CSC_TP_CONST) && o.b >= 0)) {
+                return ctx->invalid("malformed dynamics tape");
+            }
+        }
+        for (int c = 0; c < 7; ++c) {
+            if (cfg->tape_rhs[c] < 0 || static_cast<uint32_t>(cfg->tape_rhs[c]) >= cfg->tape_nslots) {
+                return ctx->invalid("malformed dynamics tape (right-hand sides)");
+            }
+        }
+        if (cfg->npars != 0u && cfg->d_pars == nullptr) {
+            return ctx->invalid("the dynamics use runtime parameters but no parameter array was given");
+        }
     }
     if ((cfg->dyn_kind & CSC_DYN_DRAG) && (cfg->d_pars == nullptr || cfg->npars == 0u)) {
         return ctx->invalid("drag needs the runtime parameter array (BSTAR)");
@@ -390,6 +425,30 @@ int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
 
 static int scan_impl(csc_ctx *ctx, const uint32_t *d_in, uint64_t n, uint32_t nseg, uint64_t *d_out64,
                      uint32_t *d_out32);
+
+// Tape dynamics: uploads the tape when it differs from the cached copy and sizes the workspace
+// for `grid` resident waves. Fills the tape fields of p.
+static int bind_tape(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, csc::prop_params &p, dim3 &grid)
+{
+    static_assert(sizeof(csc_tape_op) == sizeof(csc::tape_op), "tape layout");
+    const size_t bytes = static_cast<size_t>(cfg->tape_nops) * sizeof(csc_tape_op);
+    CSC_BUF(d_tape, csc::tape_op, "tape_ops", cfg->tape_nops);
+    if (ctx->tape_host.size() != cfg->tape_nops || std::memcmp(ctx->tape_host.data(), cfg->tape, bytes) != 0) {
+        ctx->tape_host.assign(cfg->tape, cfg->tape + cfg->tape_nops);
+        CSC_HIP(hipMemcpyAsync(d_tape, ctx->tape_host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    // At most 8 waves per CU resident (256 CUs): more would only add workspace.
+    const uint32_t ngroups = cdiv(n, 64);
+    grid = dim3(std::min<uint32_t>(ngroups, 2048u));
+    const size_t per_wave = static_cast<size_t>(cfg->tape_nslots) * 21u * 64u;
+    CSC_BUF(d_ws, double, "tape_ws", per_wave * grid.x);
+    p.tape = d_tape;
+    p.tape_nops = cfg->tape_nops;
+    p.tape_nslots = cfg->tape_nslots;
+    p.tape_ws = d_ws;
+    return CSC_OK;
+}
 
 extern "C" {
 
@@ -597,7 +656,12 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
     p.ubs = d_ubs;
     p.recs = d_recs;
     const bool events = cfg->has_exit || cfg->has_reentry;
-    const dim3 grid(cdiv(n, 64)), block(64);
+    dim3 grid(cdiv(n, 64)), block(64);
+    if (cfg->dyn_kind == CSC_DYN_TAPE) {
+        if (const int rc = bind_tape(ctx, cfg, n, p, grid)) {
+            return rc;
+        }
+    }
     KT("k_propagate", launch_propagate<false>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
@@ -632,7 +696,12 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
     p.tcs_vr = d_tcs_vr;
     p.tcoords = d_tcoords;
     const bool events = cfg->has_exit || cfg->has_reentry;
-    const dim3 grid(cdiv(n, 64)), block(64);
+    dim3 grid(cdiv(n, 64)), block(64);
+    if (cfg->dyn_kind == CSC_DYN_TAPE) {
+        if (const int rc = bind_tape(ctx, cfg, n, p, grid)) {
+            return rc;
+        }
+    }
     KT("k_propagate_store", launch_propagate<true>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;

@@ -94,7 +94,77 @@ PYBIND11_MODULE(core, m)
 {
     m.doc() = "MI355X-native cascade.core";
 
+    // Expressions for user-defined dynamics (the role heyoka.py's expression class plays in the
+    // reference's Python API, cascade.py/__init__.py:47-61): cascade_amd.dynamics re-exports them.
+    py::class_<expression>(m, "expression")
+        .def(py::init<double>())
+        .def(py::init<std::string>())
+        .def("__repr__",
+             [](const expression &e) {
+                 std::ostringstream oss;
+                 oss << e;
+                 return oss.str();
+             })
+        .def("__neg__", [](const expression &a) { return -a; })
+        .def("__pos__", [](const expression &a) { return a; })
+        .def("__add__", [](const expression &a, const expression &b) { return a + b; })
+        .def("__add__", [](const expression &a, double b) { return a + expression(b); })
+        .def("__radd__", [](const expression &a, double b) { return expression(b) + a; })
+        .def("__sub__", [](const expression &a, const expression &b) { return a - b; })
+        .def("__sub__", [](const expression &a, double b) { return a - expression(b); })
+        .def("__rsub__", [](const expression &a, double b) { return expression(b) - a; })
+        .def("__mul__", [](const expression &a, const expression &b) { return a * b; })
+        .def("__mul__", [](const expression &a, double b) { return a * expression(b); })
+        .def("__rmul__", [](const expression &a, double b) { return expression(b) * a; })
+        .def("__truediv__", [](const expression &a, const expression &b) { return a / b; })
+        .def("__truediv__", [](const expression &a, double b) { return a / expression(b); })
+        .def("__rtruediv__", [](const expression &a, double b) { return expression(b) / a; })
+        .def("__pow__", [](const expression &a, double e) { return pow(a, e); })
+        .def("__pow__", [](const expression &a, const expression &e) { return pow(a, e); });
+    py::implicitly_convertible<double, expression>();
+    m.def("_ex_sin", [](const expression &a) { return sin(a); });
+    m.def("_ex_cos", [](const expression &a) { return cos(a); });
+    m.def("_ex_exp", [](const expression &a) { return exp(a); });
+    m.def("_ex_sqrt", [](const expression &a) { return sqrt(a); });
+    m.def("_ex_pow", [](const expression &a, double e) { return pow(a, e); });
+    m.def("_ex_diff", [](const expression &e, const expression &v) { return diff(e, v); });
+    m.def("_ex_par", [](std::uint32_t i) { return par(i); });
+    m.def("_ex_time", []() { return time_expr; });
+
+    // The lowered form of six equations: what the propagation kernel interprets (and what the
+    // tests hand to the CPU oracle as the dynamics definition).
+    PYBIND11_NUMPY_DTYPE(tape_op, op, dst, a, b, c);
+    auto tape_dict = [](const std::vector<dynamics::dyn_t::eq_t> &eqs) {
+        const tape_t t = lower_dynamics(eqs);
+        py::array_t<tape_op> ops(static_cast<py::ssize_t>(t.ops.size()));
+        std::copy(t.ops.begin(), t.ops.end(), ops.mutable_data());
+        py::dict d;
+        d["ops"] = ops;
+        d["nslots"] = t.nslots;
+        d["rhs"] = py::array_t<std::int32_t>(7, t.rhs.data());
+        d["npars"] = t.npars;
+        return d;
+    };
+    m.def("lower_dynamics", tape_dict);
+
     py::class_<dynamics::dyn_t>(m, "dyn_t")
+        .def(py::init<std::vector<dynamics::dyn_t::eq_t>>())
+        .def("__len__", &dynamics::dyn_t::size)
+        .def("__getitem__",
+             [](const dynamics::dyn_t &d, std::size_t i) {
+                 if (i >= d.size()) {
+                     throw py::index_error();
+                 }
+                 return d[i];
+             })
+        .def("__setitem__",
+             [](dynamics::dyn_t &d, std::size_t i, dynamics::dyn_t::eq_t e) {
+                 if (i >= d.size()) {
+                     throw py::index_error();
+                 }
+                 d[i] = std::move(e);
+             })
+        .def_property_readonly("tape", [tape_dict](const dynamics::dyn_t &d) { return tape_dict(d.eqs); })
         .def_readonly("mu", &dynamics::dyn_t::mu)
         .def_readonly("npars", &dynamics::dyn_t::npars)
         .def_readonly("J2", &dynamics::dyn_t::J2)
@@ -105,7 +175,11 @@ PYBIND11_MODULE(core, m)
         .def_property_readonly("kind", [](const dynamics::dyn_t &d) { return d.kind; })
         .def("__repr__", [](const dynamics::dyn_t &d) {
             std::ostringstream oss;
-            oss << "dynamics(kepler mu=" << d.mu << ((d.kind & 1) ? ", J2" : "") << ((d.kind & 2) ? ", drag" : "") << ")";
+            if (d.kind == dynamics::dyn_t::tape) {
+                oss << "dynamics(" << d.size() << " equations, interpreted from a tape)";
+            } else {
+                oss << "dynamics(kepler mu=" << d.mu << ((d.kind & 1) ? ", J2" : "") << ((d.kind & 2) ? ", drag" : "") << ")";
+            }
             return oss.str();
         });
     m.def("_kepler", &dynamics::kepler, "mu"_a = 1.);
@@ -126,14 +200,21 @@ PYBIND11_MODULE(core, m)
     using whitelist_t = sim::whitelist_t;
     py::class_<sim>(m, "sim", py::dynamic_attr{})
         .def(py::init<>())
-        .def(py::init([](const py::array_t<double> &state, double ct, std::optional<dynamics::dyn_t> dyn_,
+        .def(py::init([](const py::array_t<double> &state, double ct,
+                         std::optional<std::variant<dynamics::dyn_t, std::vector<dynamics::dyn_t::eq_t>>> dyn_,
                          std::optional<std::variant<double, std::vector<double>>> reentry_radius_,
                          std::optional<double> exit_radius_, const std::optional<py::array_t<double>> &pars_,
                          std::optional<double> tol_, bool ha, bool cm, std::uint32_t n_par_ct, double conj_thresh,
                          double min_coll_radius, whitelist_t coll_whitelist, whitelist_t conj_whitelist, int device) {
                  check_state_array(state);
                  sim::options o;
-                 o.dyn = dyn_ ? *dyn_ : dynamics::kepler();
+                 if (!dyn_) {
+                     o.dyn = dynamics::kepler();
+                 } else if (auto *dd = std::get_if<dynamics::dyn_t>(&*dyn_)) {
+                     o.dyn = std::move(*dd);
+                 } else {
+                     o.dyn = dynamics::dyn_t(std::move(std::get<1>(*dyn_)));
+                 }
                  o.reentry_radius = reentry_radius_ ? std::move(*reentry_radius_) : std::variant<double, std::vector<double>>{0.};
                  o.exit_radius = exit_radius_ ? *exit_radius_ : 0.;
                  o.pars = pars_vector(pars_, state.shape(0));

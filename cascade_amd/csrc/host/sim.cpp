@@ -29,44 +29,202 @@ namespace cascade
 namespace dynamics
 {
 
+namespace
+{
+
+constexpr double pi = 3.14159265358979323846;
+constexpr double deg = pi / 180.;
+
+struct state_vars {
+    expression x{"x"}, y{"y"}, z{"z"}, vx{"vx"}, vy{"vy"}, vz{"vz"};
+};
+
+// x' = vx, ..., v' = -mu r / |r|^3 (src/sim_dynamics.cpp:25-42).
+std::vector<dyn_t::eq_t> kepler_eqs(double mu)
+{
+    const state_vars v;
+    const auto w = expression(-mu) * pow(v.x * v.x + v.y * v.y + v.z * v.z, -1.5);
+    return {{v.x, v.vx}, {v.y, v.vy}, {v.z, v.vz}, {v.vx, v.x * w}, {v.vy, v.y * w}, {v.vz, v.z * w}};
+}
+
+void add_acc(std::vector<dyn_t::eq_t> &eqs, const expression &ax, const expression &ay, const expression &az)
+{
+    eqs[3].second += ax;
+    eqs[4].second += ay;
+    eqs[5].second += az;
+}
+
+// Acceleration -grad(u) of a potential-like term u.
+void add_potential(std::vector<dyn_t::eq_t> &eqs, const expression &u, const state_vars &v)
+{
+    add_acc(eqs, -diff(u, v.x), -diff(u, v.y), -diff(u, v.z));
+}
+
+} // namespace
+
 dyn_t kepler(double mu)
 {
     dyn_t d;
     d.kind = dyn_t::kepler;
     d.mu = mu;
     d.npars = 0;
+    d.eqs = kepler_eqs(mu);
     return d;
 }
 
+// cascade.py/dynamics/_simple_earth.py:86-411 (constants :136-153; all in SI units).
 dyn_t simple_earth(bool J2, bool J3, bool J4, bool C22S22, bool sun, bool moon, bool SRP, bool drag, bool thermonets)
 {
-    const std::pair<bool, const char *> missing[] = {{J3, "J3"},   {J4, "J4"},   {C22S22, "C22S22"},        {sun, "sun"},
-                                                     {moon, "moon"}, {SRP, "SRP"}, {thermonets, "thermonets"}};
-    for (const auto &[on, name] : missing) {
-        if (on) {
-            throw std::invalid_argument(std::string("simple_earth(): the term '") + name
-                                        + "' is not built into the HIP kernels (available: J2, drag)");
-        }
+    if (thermonets) {
+        throw std::invalid_argument("simple_earth(): the thermonets density model (a neural network evaluated by "
+                                    "heyoka) is not available in this build; use the exponential density fit");
     }
-    if (drag && !J2) {
-        throw std::invalid_argument("simple_earth(): drag without J2 is not built into the HIP kernels");
-    }
-    // Constants of _simple_earth.py:136-166 (SI units).
+    const double GMe = 3.986004407799724e5 * 1e9, GMsun = 1.32712440018e11 * 1e9, GMmoon = 4.9028e3 * 1e9;
+    const double Re = 6378.1363 * 1000;
+    const state_vars v;
+    const auto &x = v.x, &y = v.y, &z = v.z;
+    const auto t = time_expr;
+
     dyn_t d;
-    d.mu = 3.986004407799724e5 * 1e9;
-    d.Re = 6378.1363 * 1000;
-    d.kind = dyn_t::kepler;
+    d.mu = GMe;
+    d.Re = Re;
+    d.eqs = kepler_eqs(GMe);
+    auto &eqs = d.eqs;
+    const auto r2 = x * x + y * y + z * z;
+    const auto z2 = z * z;
+
+    // Zonal harmonics :169-200: potentials u_Jn, acceleration -grad u_Jn.
     if (J2) {
-        d.kind |= dyn_t::j2;
-        d.J2 = 0.1082635854 * 1e-2;
+        const double k = 0.1082635854e-2 * GMe * Re * Re;
+        add_potential(eqs, expression(k / 2) * (3. * z2 - r2) * pow(r2, -2.5), v);
+    }
+    if (J3) {
+        const double k = -0.2532435346e-5 * GMe * Re * Re * Re;
+        add_potential(eqs, expression(k / 2) * z * (5. * z2 - 3. * r2) * pow(r2, -3.5), v);
+    }
+    if (J4) {
+        const double k = -0.1619331205e-5 * GMe * Re * Re * Re * Re;
+        add_potential(eqs, expression(k / 8) * (35. * z2 * z2 - 30. * r2 * z2 + 3. * r2 * r2) * pow(r2, -4.5), v);
+    }
+    // Tesseral C22 / S22 in the Earth-fixed frame :202-242.
+    if (C22S22) {
+        const double C22 = 2.43914352398e-6, S22 = -1.40016683654e-6;
+        const double theta_g = deg * 280.4606, nu_e = deg * 4.178074622024230e-3;
+        const double k15 = GMe * Re * Re * std::sqrt(15.);
+        const auto ang = theta_g + nu_e * t;
+        const auto c = cos(ang), s = sin(ang);
+        const auto X = x * c + y * s, Y = y * c - x * s;
+        const auto &Z = z;
+        const auto q7 = pow(r2, -3.5), q5 = pow(r2, -2.5);
+        const auto c1 = expression(5 * k15 * C22 / 2) * q7, c2 = expression(k15 * C22) * q5;
+        const auto s1 = expression(5 * k15 * S22) * q7, s2 = expression(k15 * S22) * q5;
+        const auto dd = Y * Y - X * X;
+        const auto FX = (c1 * X * dd + c2 * X) + (s2 * Y - s1 * (X * X) * Y);
+        const auto FY = (c1 * Y * dd - c2 * Y) + (s2 * X - s1 * X * (Y * Y));
+        const auto FZ = c1 * Z * dd - s1 * X * Y * Z;
+        add_acc(eqs, FX * c - FY * s, FX * s + FY * c, FZ);
+    }
+    // Position of the Sun :244-258.
+    expression Xo, Yo, Zo, dist_sun2;
+    if (sun || SRP) {
+        const double eps = deg * 23.4392911, nu_o = deg * 1.1407410259335311e-5;
+        const auto lo = deg * 357.5256 + nu_o * t;
+        const auto lam = deg * 282.94 + lo + deg * ((6892. / 3600) * sin(lo) + (72. / 3600) * sin(2. * lo));
+        const auto ro = (149.619 - 2.499 * cos(lo) - 0.021 * cos(2. * lo)) * 1e9;
+        Xo = ro * cos(lam);
+        Yo = ro * sin(lam) * std::cos(eps);
+        Zo = ro * sin(lam) * std::sin(eps);
+        dist_sun2 = (x - Xo) * (x - Xo) + (y - Yo) * (y - Yo) + (z - Zo) * (z - Zo);
+    }
+    // Third-body gravity -GM ((r - R) / |r - R|^3 + R / |R|^3).
+    auto third_body = [&](double GM, const expression &X, const expression &Y, const expression &Z, const expression &d2) {
+        const auto a3 = pow(d2, -1.5), b3 = pow(X * X + Y * Y + Z * Z, -1.5);
+        add_acc(eqs, expression(-GM) * ((x - X) * a3 + X * b3), expression(-GM) * ((y - Y) * a3 + Y * b3),
+                expression(-GM) * ((z - Z) * a3 + Z * b3));
+    };
+    if (sun) {
+        third_body(GMsun, Xo, Yo, Zo, dist_sun2);
+    }
+    if (moon) {
+        // :277-363: truncated lunar theory; {coefficient, multiples of lm, llm, Fm, Dm}.
+        const double eps = deg * 23.4392911;
+        const double nu_o = deg * 1.1407410259335311e-5, nu_ma = deg * 1.512151961904581e-4,
+                     nu_mp = deg * 1.2893925235125941e-6, nu_ms = deg * 6.128913003523574e-7;
+        const auto L0 = (nu_mp + nu_ma) * t + deg * 218.31617;
+        const auto lm = nu_ma * t + deg * 134.96292;
+        const auto llm = nu_o * t + deg * 357.5256;
+        const auto Fm = (nu_mp + nu_ma + nu_ms) * t + deg * 93.27283;
+        const auto Dm = (nu_mp + nu_ma - nu_o) * t + deg * 297.85027;
+        struct term {
+            double c;
+            int lm, llm, Fm, Dm;
+        };
+        auto arg = [&](const term &k) {
+            return static_cast<double>(k.lm) * lm + static_cast<double>(k.llm) * llm + static_cast<double>(k.Fm) * Fm
+                   + static_cast<double>(k.Dm) * Dm;
+        };
+        const term rterms[] = {{-20905, 1, 0, 0, 0}, {-3699, -1, 0, 0, 2}, {-2956, 0, 0, 0, 2}, {-570, 2, 0, 0, 0},
+                               {246, 2, 0, 0, -2},   {-205, 0, 1, 0, -2},  {-171, 1, 0, 0, 2},  {-152, 1, 1, 0, -2}};
+        expression rm(385000.);
+        for (const auto &k : rterms) {
+            rm += k.c * cos(arg(k));
+        }
+        rm = rm * 1000.;
+        const term lterms[] = {{22640, 1, 0, 0, 0},  {769, 2, 0, 0, 0},    {-4856, 1, 0, 0, -2}, {2370, 0, 0, 0, 2},
+                               {-668, 0, 1, 0, 0},   {-412, 0, 0, 2, 0},   {-212, 2, 0, 0, -2},  {-206, 1, 1, 0, -2},
+                               {192, 1, 0, 0, 2},    {-165, 0, 1, 0, -2},  {148, 1, -1, 0, 0},   {-125, 0, 0, 0, 1},
+                               {-110, 1, 1, 0, 0},   {-55, 0, 0, 2, -2}};
+        expression lsum(0.);
+        for (const auto &k : lterms) {
+            lsum += (k.c / 3600) * sin(arg(k));
+        }
+        const auto lam = L0 + deg * lsum;
+        const term bterms[] = {{-526, 0, 0, 1, -2}, {44, 1, 0, 1, -2}, {-31, -1, 0, 1, -2}, {-25, -2, 0, 1, 0},
+                               {-23, 0, 1, 1, -2},  {21, -1, 0, 1, 0}, {11, 0, -1, 1, -2}};
+        expression bsum = (18520. / 3600)
+                          * sin(Fm + lam - L0 + deg * ((412. / 3600) * sin(2. * Fm) + (541. / 3600) * sin(llm)));
+        for (const auto &k : bterms) {
+            bsum += (k.c / 3600) * sin(arg(k));
+        }
+        const auto Bm = deg * bsum;
+        const auto cB = cos(Bm), sB = sin(Bm), cl = cos(lam), sl = sin(lam);
+        const auto Xm = cB * cl * rm;
+        const auto Ym = std::cos(eps) * cB * sl * rm - std::sin(eps) * sB * rm;
+        const auto Zm = std::cos(eps) * sB * rm + std::sin(eps) * cB * sl * rm;
+        third_body(GMmoon, Xm, Ym, Zm, (x - Xm) * (x - Xm) + (y - Ym) * (y - Ym) + (z - Zm) * (z - Zm));
     }
     if (drag) {
-        d.kind |= dyn_t::drag;
+        // :365-387 with the density fit :16-46 (beta per metre, gamma in metres); par[0] = BSTAR.
         d.npars = 1;
-        // The fitted density constants (_simple_earth.py:24-44): beta per metre, gamma in metres.
         d.dens_alpha = {1.01709935e-06, 7.86443375e-01, 7.50341883e-09, 8.63934252e-14};
         d.dens_beta = {4.63822910e-02 / 1000, 1.86080048e-01 / 1000, 2.48667176e-02 / 1000, 4.81080852e-03 / 1000};
         d.dens_gamma = {5.01594516e00 * 1000, 2.28429809e01 * 1000, 4.27957829e00 * 1000, 1.56291673e-01 * 1000};
+        const auto h = sqrt(r2) - Re;
+        expression rho(0.);
+        for (int k = 0; k < 4; ++k) {
+            rho += d.dens_alpha[k] * exp((d.dens_gamma[k] - h) * d.dens_beta[k]);
+        }
+        const auto vmag = sqrt(v.vx * v.vx + v.vy * v.vy + v.vz * v.vz);
+        const auto fd = rho * (1. / (0.1570 / Re)) * par(0) * vmag;
+        add_acc(eqs, -(fd * v.vx), -(fd * v.vy), -(fd * v.vz));
+    }
+    if (SRP) {
+        // :390-409: par index of Cr A/m follows BSTAR when drag is on.
+        const std::uint32_t ip = drag ? 1u : 0u;
+        d.npars = ip + 1u;
+        const double P_SI = 4.56e-3 / 1000, AU = 1.49619e8 * 1000;
+        const auto k = par(ip) * (P_SI * AU * AU) * pow(dist_sun2, -1.5);
+        add_acc(eqs, k * (x - Xo), k * (y - Yo), k * (z - Zo));
+    }
+    // The hand-unrolled kernels cover Kepler, + J2 and + J2 + drag; the rest runs from the tape.
+    const bool others = J3 || J4 || C22S22 || sun || moon || SRP;
+    if (others || (drag && !J2)) {
+        d.kind = dyn_t::tape;
+    } else {
+        d.kind = dyn_t::kepler | (J2 ? dyn_t::j2 : 0) | (drag ? dyn_t::drag : 0);
+        if (J2) {
+            d.J2 = 0.1082635854e-2;
+        }
     }
     return d;
 }
@@ -153,6 +311,7 @@ std::uint32_t order_from_tol(double tol)
 // here the device context and the grow-only device buffers.
 struct sim::sim_data {
     dynamics::dyn_t dyn;
+    tape_t tape; // the lowered equations when dyn.kind == tape
     double tol = 0;
     bool high_accuracy = false, compact_mode = false;
     std::uint32_t order = 0;
@@ -175,7 +334,7 @@ struct sim::sim_data {
     sim_data() = default;
     // A copy shares nothing on the device: it gets its own context on its first step().
     sim_data(const sim_data &o)
-        : dyn(o.dyn), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
+        : dyn(o.dyn), tape(o.tape), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
           shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange)
     {
@@ -314,13 +473,22 @@ void sim::finalise_ctor(options o)
     m_coll_whitelist = std::move(o.coll_whitelist);
     m_conj_whitelist = std::move(o.conj_whitelist);
 
-    if (o.dyn.kind != dynamics::dyn_t::kepler && o.dyn.kind != dynamics::dyn_t::j2
-        && o.dyn.kind != (dynamics::dyn_t::j2 | dynamics::dyn_t::drag)) {
-        throw std::invalid_argument("Unknown built-in dynamics kind " + std::to_string(o.dyn.kind));
+    // src/sim_basic.cpp:405-455: default dynamics, six equations, variable names, parameters.
+    if (o.dyn.empty() && o.dyn.kind == dynamics::dyn_t::kepler) {
+        o.dyn = dynamics::kepler(o.dyn.mu);
     }
-    if (!std::isfinite(o.dyn.mu) || o.dyn.mu <= 0) {
-        throw std::invalid_argument("The mu parameter of the dynamics must be finite and positive, but it is "
-                                    + fmt_d(o.dyn.mu) + " instead");
+    if (o.dyn.kind == dynamics::dyn_t::tape) {
+        m_data->tape = lower_dynamics(o.dyn.eqs);
+        o.dyn.npars = m_data->tape.npars;
+    } else {
+        if (o.dyn.kind != dynamics::dyn_t::kepler && o.dyn.kind != dynamics::dyn_t::j2
+            && o.dyn.kind != (dynamics::dyn_t::j2 | dynamics::dyn_t::drag)) {
+            throw std::invalid_argument("Unknown built-in dynamics kind " + std::to_string(o.dyn.kind));
+        }
+        if (!std::isfinite(o.dyn.mu) || o.dyn.mu <= 0) {
+            throw std::invalid_argument("The mu parameter of the dynamics must be finite and positive, but it is "
+                                        + fmt_d(o.dyn.mu) + " instead");
+        }
     }
     m_data->dyn = o.dyn;
     m_npars = o.dyn.npars;
@@ -793,6 +961,15 @@ outcome sim::step()
     }
     cfg.d_pars = d_pars;
     cfg.npars = m_npars;
+    if (d.dyn.kind == dynamics::dyn_t::tape) {
+        static_assert(sizeof(tape_op) == sizeof(csc_tape_op), "tape layout");
+        cfg.tape = reinterpret_cast<const csc_tape_op *>(d.tape.ops.data());
+        cfg.tape_nops = static_cast<std::uint32_t>(d.tape.ops.size());
+        cfg.tape_nslots = d.tape.nslots;
+        for (int k = 0; k < 7; ++k) {
+            cfg.tape_rhs[k] = d.tape.rhs[k];
+        }
+    }
     cfg.rhofac = std::exp(-0.7 / (d.order - 1)) / (std::exp(1.) * std::exp(1.));
     cfg.init_time_hi = d.time.hi;
     cfg.init_time_lo = d.time.lo;

@@ -39,6 +39,19 @@ enum : int {
     DYN_KEPLER = 0,
     DYN_J2 = 1,   // :169-178
     DYN_DRAG = 2, // :365-387 with the exponential density fit :16-46; par[0] = BSTAR
+    // General right-hand sides (the reference's heyoka expressions, sim.hpp:213-222) lowered to a
+    // tape of Taylor-series operations and interpreted order by order; see tape_compute_tcs.
+    DYN_TAPE = 0x100,
+};
+
+// One tape operation (layout of csc_tape_op, include/cascade_hip.h). Slots 0..5 = x, y, z, vx,
+// vy, vz, slot 6 = r; b is a slot (>= 0), the immediate c (-1) or runtime parameter -2 - b.
+struct tape_op {
+    std::int32_t op, dst, a, b;
+    double c;
+};
+enum : std::int32_t {
+    TP_ADD = 1, TP_SUB, TP_RSUB, TP_MUL, TP_DIV, TP_RDIV, TP_SQR, TP_POW, TP_SQRT, TP_EXP, TP_SINCOS, TP_TIME, TP_CONST
 };
 
 enum : int {
@@ -65,6 +78,13 @@ struct prop_params {
     double dens_alpha[4], dens_beta[4], dens_gamma[4];
     const double *pars; // [N][npars] runtime parameters (BSTAR = pars[i * npars]); null if npars == 0
     std::uint32_t npars;
+    // Tape dynamics (DYN_TAPE): the operations, the slot of each right-hand side and the
+    // workspace, one block of tape_nslots * (P + 1) * 64 doubles per resident wave
+    // ([slot][order][lane]: every access of a wave is one coalesced 512-byte line).
+    const tape_op *tape;
+    std::uint32_t tape_nops, tape_nslots;
+    std::int32_t tape_rhs[7];
+    double *tape_ws;
     // Terminal events (src/sim_basic.cpp:509-578): g = (kx x^2 + ky y^2) + kz z^2 - c0.
     int has_exit;
     double exit_c0;
@@ -284,9 +304,204 @@ struct dyn_order {
 // Normalised Taylor coefficients (orders 1..P) of the 7 state variables; order 0 must be
 // set by the caller. Kepler RHS src/sim_dynamics.cpp:36-41, r equation src/sim_basic.cpp:469,
 // J2 and drag cascade.py/dynamics/_simple_earth.py:169-178, 365-387.
-template <int P, int DYN>
-CSC_DEV void compute_tcs(tc_regs<P> &t, const prop_params &prm, double bstar)
+// a0^c at order 0 of a power series: exact arithmetic when 2c is a small integer (all the
+// exponents of the reference's dynamics are -3/2, -5/2, -7/2, ...), det_pow otherwise. Same
+// operations as oracle/orc.hpp::pow_order0.
+CSC_DEV double pow_order0(double a0, double c)
 {
+    const double k2 = 2. * c;
+    if (k2 == floor(k2) && fabs(k2) <= 64.) {
+        const int k = static_cast<int>(k2), m = k < 0 ? -k : k;
+        double r = (m % 2) ? sqrt(a0) : 1.;
+        for (int i = 0; i < m / 2; ++i) {
+            r = r * a0;
+        }
+        return k < 0 ? 1. / r : r;
+    }
+    return det_pow(a0, c);
+}
+
+// Per-object context of the tape interpreter.
+struct tape_ctx {
+    double *ws;         // this lane's column of the wave's workspace
+    const double *pars; // runtime parameters of the object
+    double time0;       // simulation time at the start of the substep
+};
+
+// Tape dynamics: coefficients of every slot, order by order (the automatic-differentiation
+// recurrences of SURVEY appendix A; same operations in the same order as
+// oracle/orc.hpp::tape_compute_tcs), then x_k^[n+1] = rhs_k^[n] / (n + 1). The tape is
+// wave-uniform (scalar loads, scalar branches); the series live in the workspace
+// [slot][order][lane], so every load and store of a wave is one coalesced line. Replaces the
+// Taylor step function heyoka JIT-compiles from kw::dyn (src/sim_basic.cpp:553-577, EXTERNAL).
+template <int P>
+CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_ctx &tx)
+{
+    constexpr int L = P + 1;
+    double *ws = tx.ws;
+#define CSC_AT(slot, n) ws[(static_cast<std::size_t>(slot) * L + (n)) * 64u]
+    CSC_AT(0, 0) = t.x[0];
+    CSC_AT(1, 0) = t.y[0];
+    CSC_AT(2, 0) = t.z[0];
+    CSC_AT(3, 0) = t.vx[0];
+    CSC_AT(4, 0) = t.vy[0];
+    CSC_AT(5, 0) = t.vz[0];
+    CSC_AT(6, 0) = t.r[0];
+    for (int n = 0; n < P; ++n) {
+        const double dn = static_cast<double>(n);
+        for (std::uint32_t k = 0; k < prm.tape_nops; ++k) {
+            const tape_op o = prm.tape[k];
+            const bool bs = o.b < 0;
+            double sc = o.c;
+            if (o.b <= -2) {
+                sc = tx.pars[-2 - o.b];
+            }
+            double res;
+            switch (o.op) {
+                case TP_ADD:
+                    res = bs ? (n == 0 ? CSC_AT(o.a, 0) + sc : CSC_AT(o.a, n)) : CSC_AT(o.a, n) + CSC_AT(o.b, n);
+                    break;
+                case TP_SUB:
+                    res = bs ? (n == 0 ? CSC_AT(o.a, 0) - sc : CSC_AT(o.a, n)) : CSC_AT(o.a, n) - CSC_AT(o.b, n);
+                    break;
+                case TP_RSUB:
+                    res = n == 0 ? sc - CSC_AT(o.a, 0) : -CSC_AT(o.a, n);
+                    break;
+                case TP_MUL:
+                    if (bs) {
+                        res = CSC_AT(o.a, n) * sc;
+                    } else {
+                        double acc = 0;
+                        for (int j = 0; j <= n; ++j) {
+                            acc = fma(CSC_AT(o.a, j), CSC_AT(o.b, n - j), acc);
+                        }
+                        res = acc;
+                    }
+                    break;
+                case TP_DIV:
+                    if (bs) {
+                        res = CSC_AT(o.a, n) / sc;
+                    } else {
+                        double acc = CSC_AT(o.a, n);
+                        for (int j = 1; j <= n; ++j) {
+                            acc = fma(-CSC_AT(o.b, j), CSC_AT(o.dst, n - j), acc);
+                        }
+                        res = acc / CSC_AT(o.b, 0);
+                    }
+                    break;
+                case TP_RDIV: {
+                    double acc = n == 0 ? sc : 0.;
+                    for (int j = 1; j <= n; ++j) {
+                        acc = fma(-CSC_AT(o.a, j), CSC_AT(o.dst, n - j), acc);
+                    }
+                    res = acc / CSC_AT(o.a, 0);
+                    break;
+                }
+                case TP_SQR:
+                    if (n == 0) {
+                        const double a0 = CSC_AT(o.a, 0);
+                        res = a0 * a0;
+                    } else {
+                        double acc = 0;
+                        for (int j = 0; 2 * j < n; ++j) {
+                            acc = fma(CSC_AT(o.a, j), CSC_AT(o.a, n - j), acc);
+                        }
+                        acc = acc + acc;
+                        if (n % 2 == 0) {
+                            const double am = CSC_AT(o.a, n / 2);
+                            acc = fma(am, am, acc);
+                        }
+                        res = acc;
+                    }
+                    break;
+                case TP_POW:
+                    if (n == 0) {
+                        res = pow_order0(CSC_AT(o.a, 0), o.c);
+                    } else {
+                        double acc = 0;
+                        for (int j = 0; j < n; ++j) {
+                            const double cf = dn * o.c - static_cast<double>(j) * (o.c + 1.);
+                            acc = fma(cf * CSC_AT(o.a, n - j), CSC_AT(o.dst, j), acc);
+                        }
+                        res = acc / (dn * CSC_AT(o.a, 0));
+                    }
+                    break;
+                case TP_SQRT:
+                    if (n == 0) {
+                        res = sqrt(CSC_AT(o.a, 0));
+                    } else {
+                        double acc = CSC_AT(o.a, n);
+                        for (int j = 1; j < n; ++j) {
+                            acc = fma(-CSC_AT(o.dst, j), CSC_AT(o.dst, n - j), acc);
+                        }
+                        res = acc / (2. * CSC_AT(o.dst, 0));
+                    }
+                    break;
+                case TP_EXP:
+                    if (n == 0) {
+                        res = det_exp(CSC_AT(o.a, 0));
+                    } else {
+                        double acc = 0;
+                        for (int j = 1; j <= n; ++j) {
+                            acc = fma(static_cast<double>(j) * CSC_AT(o.a, j), CSC_AT(o.dst, n - j), acc);
+                        }
+                        res = acc / dn;
+                    }
+                    break;
+                case TP_SINCOS: {
+                    double cres;
+                    if (n == 0) {
+                        const double a0 = CSC_AT(o.a, 0);
+                        res = sin(a0);
+                        cres = cos(a0);
+                    } else {
+                        double as = 0, ac = 0;
+                        for (int j = 1; j <= n; ++j) {
+                            const double ja = static_cast<double>(j) * CSC_AT(o.a, j);
+                            as = fma(ja, CSC_AT(o.dst + 1, n - j), as);
+                            ac = fma(ja, CSC_AT(o.dst, n - j), ac);
+                        }
+                        res = as / dn;
+                        cres = -(ac / dn);
+                    }
+                    CSC_AT(o.dst + 1, n) = cres;
+                    break;
+                }
+                case TP_TIME:
+                    res = n == 0 ? tx.time0 : (n == 1 ? 1. : 0.);
+                    break;
+                default: // TP_CONST
+                    res = n == 0 ? sc : 0.;
+                    break;
+            }
+            CSC_AT(o.dst, n) = res;
+        }
+        const double f = 1. / static_cast<double>(n + 1);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            CSC_AT(c, n + 1) = CSC_AT(prm.tape_rhs[c], n) * f;
+        }
+    }
+#pragma unroll
+    for (int n = 1; n <= P; ++n) {
+        t.x[n] = CSC_AT(0, n);
+        t.y[n] = CSC_AT(1, n);
+        t.z[n] = CSC_AT(2, n);
+        t.vx[n] = CSC_AT(3, n);
+        t.vy[n] = CSC_AT(4, n);
+        t.vz[n] = CSC_AT(5, n);
+        t.r[n] = CSC_AT(6, n);
+    }
+#undef CSC_AT
+}
+
+template <int P, int DYN>
+CSC_DEV void compute_tcs(tc_regs<P> &t, const prop_params &prm, double bstar, const tape_ctx &tx)
+{
+    if constexpr ((DYN & DYN_TAPE) != 0) {
+        tape_compute_tcs<P>(t, prm, tx);
+        return;
+    }
     dyn_aux<P> a;
     dyn_consts k;
     k.mu = prm.mu;
@@ -351,9 +566,8 @@ CSC_DEV_NOINLINE double event_first_root(const double *g_in, double h, int direc
 }
 
 template <int P, bool EVENTS, bool STORE, int DYN>
-__global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
+CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k, double *ws)
 {
-    const std::uint32_t lane_k = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_k >= prm.n) {
         return;
     }
@@ -377,6 +591,7 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
     if constexpr ((DYN & DYN_DRAG) != 0) {
         bstar = prm.pars[static_cast<std::size_t>(i) * prm.npars];
     }
+    tape_ctx tx{ws, prm.pars + static_cast<std::size_t>(i) * prm.npars, 0.};
     // src/sim_propagate.cpp:160
     t.r[0] = sqrt(t.x[0] * t.x[0] + t.y[0] * t.y[0] + t.z[0] * t.z[0]);
 
@@ -459,7 +674,8 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
         const dfl rem = df_sub(t_end, tm);
         const double max_dt = rem.hi > 0. ? rem.hi : 0.;
 
-        compute_tcs<P, DYN>(t, prm, bstar);
+        tx.time0 = tm.hi;
+        compute_tcs<P, DYN>(t, prm, bstar, tx);
 
         // Jorba-Zou step size (heyoka, EXTERNAL).
         double m0 = 0, mo = 0, mom1 = 0;
@@ -691,6 +907,22 @@ __global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
         fs[3] = t.vx[0];
         fs[4] = t.vy[0];
         fs[5] = t.vz[0];
+    }
+}
+
+// One object per lane. The built-in dynamics run one object per launched lane; tape dynamics
+// loop over the groups of 64 objects with a bounded grid, so that the workspace is sized by the
+// resident waves and not by the population.
+template <int P, bool EVENTS, bool STORE, int DYN>
+__global__ __launch_bounds__(64) void k_propagate(const prop_params prm)
+{
+    if constexpr ((DYN & DYN_TAPE) != 0) {
+        double *ws = prm.tape_ws + static_cast<std::size_t>(blockIdx.x) * prm.tape_nslots * (P + 1) * 64u + threadIdx.x;
+        for (std::uint32_t g = blockIdx.x; static_cast<std::uint64_t>(g) * 64u < prm.n; g += gridDim.x) {
+            propagate_object<P, EVENTS, STORE, DYN>(prm, g * 64u + threadIdx.x, ws);
+        }
+    } else {
+        propagate_object<P, EVENTS, STORE, DYN>(prm, blockIdx.x * blockDim.x + threadIdx.x, nullptr);
     }
 }
 

@@ -1,13 +1,67 @@
-"""Built-in dynamics descriptors.
+"""Dynamics for ``cascade_amd.sim``.
 
 The reference passes dynamics as heyoka expressions (``kw::dyn``, include/cascade/sim.hpp:213-222;
-``cascade.dynamics.kepler``, src/sim_dynamics.cpp:25-42). heyoka's JIT is replaced here by
-hand-written Taylor kernels, so ``dyn`` is a small descriptor object (``cascade::dynamics::dyn_t``)
-instead; the call signatures of the factory functions are the reference's.
+``cascade.dynamics.kepler``, src/sim_dynamics.cpp:25-42) and JIT-compiles an integrator for them.
+Here the equations are ``cascade_amd.dynamics.expression`` objects (the C++ class
+``cascade::expression``, include/cascade/expression.hpp): same way of writing them --
+``make_vars``, ``par[i]``, ``time``, ``sin``/``cos``/``exp``/``sqrt``/``pow``/``diff`` -- but lowered
+to a tape of Taylor-series operations that the GPU propagation kernel interprets. ``kepler()``
+and ``simple_earth()`` have the reference's signatures and return a list-like object of six
+``(variable, expression)`` pairs that can be modified item by item exactly like the reference's
+lists (``dyn[3] = (dyn[3][0], dyn[3][1] + f)``); untouched Kepler / J2 / J2 + drag dynamics run on
+hand-unrolled kernels.
 """
 import math
 
 from . import core
+from .core import expression, lower_dynamics  # noqa: F401
+
+
+def make_vars(*names):
+    """Variables by name (heyoka.make_vars); a single name returns a single expression."""
+    vs = [expression(str(n)) for n in names]
+    return vs[0] if len(vs) == 1 else vs
+
+
+class _Par:
+    """``par[i]``: runtime parameter ``i`` of each object (heyoka.par)."""
+
+    def __getitem__(self, i):
+        return core._ex_par(int(i))
+
+
+par = _Par()
+#: the simulation time (heyoka.time)
+time = core._ex_time()
+
+
+def _ex(a):
+    return a if isinstance(a, expression) else expression(float(a))
+
+
+def sin(a):
+    return core._ex_sin(_ex(a))
+
+
+def cos(a):
+    return core._ex_cos(_ex(a))
+
+
+def exp(a):
+    return core._ex_exp(_ex(a))
+
+
+def sqrt(a):
+    return core._ex_sqrt(_ex(a))
+
+
+def pow(a, e):  # noqa: A001
+    return core._ex_pow(_ex(a), float(e))
+
+
+def diff(e, var):
+    """Symbolic derivative of ``e`` with respect to the variable ``var`` (heyoka.diff)."""
+    return core._ex_diff(_ex(e), var)
 
 
 def kepler(mu: float = 1.0):
@@ -18,9 +72,9 @@ def kepler(mu: float = 1.0):
 
 
 def simple_earth(J2=True, J3=False, J4=False, C22S22=True, sun=False, moon=False, SRP=False, drag=True, thermonets=False):
-    """Perturbed dynamics around the Earth in SI units: signature and defaults of the reference's
-    ``cascade.dynamics.simple_earth`` (cascade.py/dynamics/_simple_earth.py:86-96). Built so
-    far: ``J2`` and ``drag`` (exponential density fit; pass every object's BSTAR as its first
-    simulation parameter, ``pars``). Any other term raises ``ValueError`` -- note that the
-    reference switches ``C22S22`` on by default, so it has to be turned off explicitly here."""
+    """Perturbed dynamics around the Earth in SI units: signature, defaults and formulas of the
+    reference's ``cascade.dynamics.simple_earth`` (cascade.py/dynamics/_simple_earth.py:86-411).
+    With ``drag`` every object's BSTAR is its first simulation parameter (``pars``), with ``SRP``
+    the term Cr*A/m follows it. ``thermonets`` (a neural density model evaluated by heyoka) is not
+    available and raises ``ValueError``."""
     return core._simple_earth(J2, J3, J4, C22S22, sun, moon, SRP, drag, thermonets)

@@ -88,3 +88,57 @@ def leo_si_population(n, seed=42, with_bstar=True):
     st = np.stack([x, y, z, vx, vy, vz, size], axis=1)
     pars = np.exp(rng.uniform(np.log(1e-5), np.log(1e-3), n)).reshape(n, 1) if with_bstar else np.zeros((n, 0))
     return np.ascontiguousarray(st), np.ascontiguousarray(pars)
+
+
+def haumea_ring(nparts=10000, seed=5489):
+    """The ring population of benchmark/haumea.cpp:142-167: a ~ U(5e6, 1e7) m, e ~ U(0, 1e-3),
+    i ~ U(0, 1 deg), angles ~ U(0, 2 pi), radius 10 km / 3; draw order a, e, i, om, Om, nu with
+    std::mt19937 left at its default seed 5489 (:73). Returns state [nparts, 7] (SI units)."""
+    G, m_c = 6.674e-11, 4.006e21
+    raw = _mt19937_raw(seed, nparts * 12).reshape(nparts * 6, 2)
+    u = _canonical(raw).reshape(nparts, 6)
+    a = (10000e3 - 5000e3) * u[:, 0] + 5000e3
+    e = 1e-3 * u[:, 1]
+    inc = (2 * np.pi / 360) * u[:, 2]
+    om, Om, nu = (2 * np.pi * u[:, k] for k in (3, 4, 5))
+    x, v = kep_to_cart_bench(a, e, inc, Om, om, nu, m_c * G)
+    st = np.empty((nparts, 7))
+    st[:, :3] = x
+    st[:, 3:6] = v
+    st[:, 6] = 10e3 / 3
+    return st
+
+
+def haumea_dynamics():
+    """The dynamics of benchmark/haumea.cpp:83-139 written with cascade_amd.dynamics expressions:
+    Kepler around Haumea, the tidal perturbation of the moon Hi'iaka on its (time-dependent)
+    Keplerian orbit in the non-inertial frame, and the MacCullagh term of Haumea's triaxial
+    ellipsoid. Returns (dyn, constants)."""
+    from . import dynamics as D
+
+    G = 6.674e-11
+    m_c = 4.006e21
+    mu_c = m_c * G
+    ra = rb = 2000e3
+    rc = ra / 2
+    Ac, Bc, Cc = (m_c / 5.0 * (p * p + q * q) for p, q in ((rb, rc), (ra, rc), (ra, rb)))
+    mu_s = m_c / 223 * G
+    a_s, e_s, inc_s = 20000e3, 0.05, 55.0 * 2 * np.pi / 360
+    x, y, z = D.make_vars("x", "y", "z")
+    M = float(np.sqrt((mu_c + mu_s) / a_s**3)) * D.time
+    sM, cM = D.sin(M), D.cos(M)
+    # Position of the moon to first order in its eccentricity.
+    xo = a_s * (cM - e_s * (1.0 + sM * sM))
+    yo = a_s * (sM + e_s * sM * cM)
+    xs, ys, zs = xo, yo * float(np.cos(inc_s)), yo * float(np.sin(inc_s))
+    dps = D.pow((xs - x) * (xs - x) + (ys - y) * (ys - y) + (zs - z) * (zs - z), -1.5)
+    dcs = D.pow(xs * xs + ys * ys + zs * zs, -1.5)
+    r2 = x * x + y * y + z * z
+    inertia = (Ac * x * x + Bc * y * y + Cc * z * z) / r2
+    vell = (G / 2.0) * ((Ac + Bc + Cc) - 3.0 * inertia) * D.pow(r2, -1.5)
+    dyn = D.kepler(mu_c)
+    for k, (q, qs) in enumerate(((x, xs), (y, ys), (z, zs))):
+        lhs, rhs = dyn[3 + k]
+        dyn[3 + k] = (lhs, rhs + mu_s * ((qs - q) * dps - qs * dcs) + D.diff(vell, q))
+    consts = dict(G=G, m_c=m_c, mu_c=mu_c, ra=ra, rb=rb, rc=rc, Ac=Ac, Bc=Bc, Cc=Cc, mu_s=mu_s, a_s=a_s, e_s=e_s, inc_s=inc_s)
+    return dyn, consts

@@ -619,18 +619,26 @@ public:
             case ex_kind::time:
                 r = slot(emit(TP_TIME, 0, 0, 0.));
                 break;
-            case ex_kind::add:
-                r = binary(TP_ADD, TP_ADD, lower(p->a), lower(p->b), true);
+            case ex_kind::add: {
+                const operand la = lower(p->a), lb = lower(p->b); // left operand first
+                r = binary(TP_ADD, TP_ADD, la, lb, true);
                 break;
-            case ex_kind::sub:
-                r = binary(TP_SUB, TP_RSUB, lower(p->a), lower(p->b), false);
+            }
+            case ex_kind::sub: {
+                const operand la = lower(p->a), lb = lower(p->b); // left operand first
+                r = binary(TP_SUB, TP_RSUB, la, lb, false);
                 break;
-            case ex_kind::mul:
-                r = binary(TP_MUL, TP_MUL, lower(p->a), lower(p->b), true);
+            }
+            case ex_kind::mul: {
+                const operand la = lower(p->a), lb = lower(p->b); // left operand first
+                r = binary(TP_MUL, TP_MUL, la, lb, true);
                 break;
-            case ex_kind::div:
-                r = binary(TP_DIV, TP_RDIV, lower(p->a), lower(p->b), false);
+            }
+            case ex_kind::div: {
+                const operand la = lower(p->a), lb = lower(p->b); // left operand first
+                r = binary(TP_DIV, TP_RDIV, la, lb, false);
                 break;
+            }
             case ex_kind::neg: {
                 const operand a = lower(p->a);
                 r = slot(emit(TP_MUL, as_slot(a), -1, -1.));

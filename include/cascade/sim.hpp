@@ -11,10 +11,12 @@
 // remove_particles(), reset_conjunctions(), the _get_*_ptr() accessors used by the Python
 // bindings, operator<<.
 //
-// The single intentional deviation: kw::dyn takes a cascade::dynamics::dyn_t descriptor
-// (dynamics::kepler(mu)) instead of a vector of heyoka expressions; heyoka and its LLVM JIT are
-// replaced by built-in dynamics integrated on the GPU. One extra named
-// argument, kw::device, selects the GPU.
+// The single intentional deviation: the equations of kw::dyn are cascade::expression objects
+// (include/cascade/expression.hpp) instead of heyoka expressions; heyoka and its LLVM JIT are
+// replaced by hand-unrolled Taylor kernels for Kepler / J2 / drag and by a tape interpreter on
+// the GPU for every other right-hand side. kw::dyn takes what dynamics::kepler()
+// and dynamics::simple_earth() return, modified or not, or any std::vector of six (variable,
+// expression) pairs. One extra named argument, kw::device, selects the GPU.
 //
 // No CPU fallback: step() needs libcascade_hip.so and a HIP device and throws
 // std::runtime_error otherwise. Construction, validation, getters and setters work anywhere.
@@ -37,6 +39,8 @@
 #include <variant>
 #include <vector>
 
+#include "expression.hpp"
+
 namespace cascade
 {
 
@@ -46,11 +50,15 @@ enum class outcome { success, time_limit, collision, reentry, exit, err_nf_state
 namespace dynamics
 {
 
-// Built-in dynamics descriptor (replaces std::vector<std::pair<heyoka::expression,
-// heyoka::expression>>, sim.hpp:213-222).
+// The dynamics of a simulation: the six equations (variable, right-hand side) of the reference's
+// std::vector<std::pair<heyoka::expression, heyoka::expression>> (sim.hpp:213-222), with
+// vector-like access, plus a tag that remembers when they are exactly one of the built-in
+// right-hand sides (Kepler, Kepler + J2, Kepler + J2 + drag) for which the propagation kernel is
+// hand-unrolled. Any write access (dyn[3].second += ...) drops the tag: the equations are then
+// lowered to a tape and interpreted on the GPU.
 struct dyn_t {
-    // Kepler plus a bit mask of perturbations.
-    enum kind_t : int { kepler = 0, j2 = 1, drag = 2 };
+    using eq_t = std::pair<expression, expression>;
+    enum kind_t : int { kepler = 0, j2 = 1, drag = 2, tape = 0x100 };
     int kind = kepler;
     double mu = 1.;
     std::uint32_t npars = 0; // runtime parameters per particle (drag: 1 = BSTAR)
@@ -58,11 +66,52 @@ struct dyn_t {
     double Re = 1.;
     // rho(h) = sum_k alpha_k exp(-(h - gamma_k) beta_k), h = r - Re (SI units)
     std::array<double, 4> dens_alpha = {}, dens_beta = {}, dens_gamma = {};
+    std::vector<eq_t> eqs;
+
+    dyn_t() = default;
+    dyn_t(std::vector<eq_t> e) : kind(tape), eqs(std::move(e)) {} // NOLINT (implicit on purpose)
+
+    [[nodiscard]] std::size_t size() const
+    {
+        return eqs.size();
+    }
+    [[nodiscard]] bool empty() const
+    {
+        return eqs.empty();
+    }
+    eq_t &operator[](std::size_t i)
+    {
+        kind = tape;
+        return eqs[i];
+    }
+    const eq_t &operator[](std::size_t i) const
+    {
+        return eqs[i];
+    }
+    void push_back(eq_t e)
+    {
+        kind = tape;
+        eqs.push_back(std::move(e));
+    }
+    [[nodiscard]] auto begin() const
+    {
+        return eqs.begin();
+    }
+    [[nodiscard]] auto end() const
+    {
+        return eqs.end();
+    }
 
     friend bool operator==(const dyn_t &a, const dyn_t &b)
     {
-        return a.kind == b.kind && a.mu == b.mu && a.npars == b.npars && a.J2 == b.J2 && a.Re == b.Re
-               && a.dens_alpha == b.dens_alpha && a.dens_beta == b.dens_beta && a.dens_gamma == b.dens_gamma;
+        if (a.kind != b.kind) {
+            return false;
+        }
+        if (a.kind == tape) {
+            return a.eqs.size() == b.eqs.size() && (a.eqs.size() != 6u || lower_dynamics(a.eqs) == lower_dynamics(b.eqs));
+        }
+        return a.mu == b.mu && a.npars == b.npars && a.J2 == b.J2 && a.Re == b.Re && a.dens_alpha == b.dens_alpha
+               && a.dens_beta == b.dens_beta && a.dens_gamma == b.dens_gamma;
     }
 };
 
@@ -70,11 +119,12 @@ struct dyn_t {
 dyn_t kepler(double mu = 1.);
 
 // Perturbed dynamics around the Earth in SI units, same signature and defaults as the
-// reference's cascade.dynamics.simple_earth (cascade.py/dynamics/_simple_earth.py:86-96). Built
-// so far: J2 (:169-178) and drag with the exponential density fit (:365-387, :16-46; the BSTAR
-// coefficient of every object is its first runtime parameter, kw::pars). Asking for a term
-// that is not built (J3, J4, C22S22 -- on by default in the reference --, sun, moon, SRP,
-// thermonets) throws std::invalid_argument.
+// reference's cascade.dynamics.simple_earth (cascade.py/dynamics/_simple_earth.py:86-96): J2,
+// J3, J4 (:169-200), C22/S22 (:202-242), Sun and Moon gravity (:244-363), drag with the
+// exponential density fit (:365-387, :16-46; the BSTAR coefficient of every object is its first
+// runtime parameter, kw::pars) and solar radiation pressure (:390-409; Cr A/m is the next
+// parameter). J2 alone and J2 + drag run on the hand-unrolled kernels, every other combination
+// on the tape interpreter. thermonets (a neural density model of heyoka) throws.
 dyn_t simple_earth(bool J2 = true, bool J3 = false, bool J4 = false, bool C22S22 = true, bool sun = false,
                    bool moon = false, bool SRP = false, bool drag = true, bool thermonets = false);
 

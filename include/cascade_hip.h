@@ -44,7 +44,34 @@ typedef enum csc_status {
  * (src/sim_dynamics.cpp:25-42) plus a bit mask of the perturbations of simple_earth()
  * (cascade.py/dynamics/_simple_earth.py): J2 (:169-178) and atmospheric drag with the 4-term
  * exponential density fit (:365-387, :16-46; runtime parameter 0 of a particle = BSTAR). */
-enum { CSC_DYN_KEPLER = 0, CSC_DYN_J2 = 1, CSC_DYN_DRAG = 2 };
+enum { CSC_DYN_KEPLER = 0, CSC_DYN_J2 = 1, CSC_DYN_DRAG = 2, CSC_DYN_TAPE = 0x100 };
+
+/* General dynamics (CSC_DYN_TAPE): the six user equations of kw::dyn (sim.hpp:213-222; what the
+ * reference hands to heyoka's JIT, src/sim_basic.cpp:405-469, 553-577) plus the equation of r
+ * (:461-469), lowered by include/cascade/expression.hpp to a tape of operations on truncated
+ * Taylor series ("slots"). Slots 0..5 are x, y, z, vx, vy, vz, slot 6 is r; every operation
+ * defines slot dst (CSC_TP_SINCOS also dst + 1 = cos). a is a slot; b is a slot (b >= 0), the
+ * immediate c (b == -1) or runtime parameter -2 - b of the object (b <= -2). The propagation
+ * kernel interprets the tape order by order, one object per lane. */
+enum {
+    CSC_TP_ADD = 1, /* a + b */
+    CSC_TP_SUB,     /* a - b */
+    CSC_TP_RSUB,    /* b - a (b scalar) */
+    CSC_TP_MUL,     /* a * b */
+    CSC_TP_DIV,     /* a / b */
+    CSC_TP_RDIV,    /* b / a (b scalar) */
+    CSC_TP_SQR,     /* a * a */
+    CSC_TP_POW,     /* a ^ c */
+    CSC_TP_SQRT,
+    CSC_TP_EXP,
+    CSC_TP_SINCOS,  /* dst = sin(a), dst + 1 = cos(a) */
+    CSC_TP_TIME,    /* the simulation time */
+    CSC_TP_CONST    /* the scalar b as a series */
+};
+typedef struct csc_tape_op {
+    int32_t op, dst, a, b;
+    double c;
+} csc_tape_op;
 
 /* Integrator + event configuration of one superstep. Replaces what sim::finalise_ctor bakes
  * into the heyoka integrators (src/sim_basic.cpp:461-578). */
@@ -74,6 +101,13 @@ typedef struct csc_prop_cfg {
     double dens_gamma[4];
     const double *d_pars;  /* DEVICE [n][npars] runtime parameters; BSTAR = d_pars[i * npars] */
     uint32_t npars;
+    /* CSC_DYN_TAPE: HOST array of tape_nops operations (copied into the context when it
+     * changes), the number of slots and the slot holding the right-hand side of x, y, z, vx, vy,
+     * vz, r. mu, J2, Re and the density fit are not used. */
+    const csc_tape_op *tape;
+    uint32_t tape_nops;
+    uint32_t tape_nslots;
+    int32_t tape_rhs[7];
 } csc_prop_cfg;
 
 /* Per-particle status written by csc_propagate: low byte 0 time limit / 1 stopping terminal

@@ -170,6 +170,20 @@ enum dyn_kind : int {
     DYN_KEPLER = 0,    // src/sim_dynamics.cpp:25-42
     DYN_KEPLER_J2 = 1, // bit 0: J2, cascade.py/dynamics/_simple_earth.py:169-178
     DYN_DRAG = 2,      // bit 1: drag with the 4-term exponential density fit, :365-387 and :16-46
+    DYN_TAPE = 0x100,  // general right-hand sides as a tape of Taylor-series operations (see tape_op)
+};
+
+// General dynamics. The reference hands arbitrary heyoka expressions to heyoka's JIT
+// (include/cascade/sim.hpp:213-222, src/sim_basic.cpp:405-469); here they arrive lowered to a
+// tape (include/cascade/expression.hpp, the dynamics definition = input data of the test). Slots
+// 0..5 = x, y, z, vx, vy, vz, slot 6 = r; operand b is a slot (>= 0), the immediate c (-1) or
+// runtime parameter -2 - b of the particle.
+struct tape_op {
+    std::int32_t op, dst, a, b;
+    double c;
+};
+enum : std::int32_t {
+    TP_ADD = 1, TP_SUB, TP_RSUB, TP_MUL, TP_DIV, TP_RDIV, TP_SQR, TP_POW, TP_SQRT, TP_EXP, TP_SINCOS, TP_TIME, TP_CONST
 };
 
 struct dynamics {
@@ -182,8 +196,15 @@ struct dynamics {
     double dens_alpha[4] = {1.01709935e-06, 7.86443375e-01, 7.50341883e-09, 8.63934252e-14};
     double dens_beta[4] = {4.63822910e-02 / 1000, 1.86080048e-01 / 1000, 2.48667176e-02 / 1000, 4.81080852e-03 / 1000};
     double dens_gamma[4] = {5.01594516e00 * 1000, 2.28429809e01 * 1000, 4.27957829e00 * 1000, 1.56291673e-01 * 1000};
+    // kind & DYN_TAPE
+    std::vector<tape_op> tape;
+    std::uint32_t tape_nslots = 0, tape_npars = 0;
+    std::int32_t tape_rhs[7] = {0, 0, 0, 0, 0, 0, 0};
     std::uint32_t npars() const
     {
+        if (kind & DYN_TAPE) {
+            return tape_npars;
+        }
         return (kind & DYN_DRAG) ? 1u : 0u; // par[0] = BSTAR (:367)
     }
 };
@@ -786,6 +807,9 @@ struct taylor_work {
     std::vector<double> u, w, g, inv;
     std::vector<double> aux[20];
     double par0 = 0; // first runtime parameter of the particle being integrated (BSTAR)
+    const double *pars = nullptr; // all runtime parameters of that particle (tape dynamics)
+    double time0 = 0;             // simulation time at the start of the substep (tape dynamics)
+    std::vector<double> ws;       // tape slots [nslots][order + 1]
     rf_scratch rfs;
     rf_stats rf_st;
     void prepare(std::uint32_t p)
@@ -840,12 +864,38 @@ inline double conv_sq(const double *a, std::uint32_t n)
 }
 
 inline double det_exp(double t);
+inline double det_pow(double x, double y);
+
+// a0^c at order 0 of a power series: exact arithmetic (multiplications, one sqrt, one division)
+// when 2c is a small integer -- every exponent of the reference's dynamics is (-3/2, -5/2,
+// -7/2, ...) --, det_pow otherwise.
+inline double pow_order0(double a0, double c)
+{
+    const double k2 = 2. * c;
+    if (k2 == std::floor(k2) && std::fabs(k2) <= 64.) {
+        const int k = static_cast<int>(k2), m = k < 0 ? -k : k;
+        double r = (m % 2) ? std::sqrt(a0) : 1.;
+        for (int i = 0; i < m / 2; ++i) {
+            r = r * a0;
+        }
+        return k < 0 ? 1. / r : r;
+    }
+    return det_pow(a0, c);
+}
+
+// Tape dynamics: Taylor coefficients of all slots, order by order (classical AD recurrences,
+// SURVEY appendix A), then x_k^[n+1] = rhs_k^[n] / (n + 1).
+inline void tape_compute_tcs(const taylor_cfg &cfg, taylor_work &wk, const double st[7]);
 
 // Normalised Taylor coefficients of the 7 state variables at the current state
 // (heyoka AD recurrences, EXTERNAL). Kepler RHS:
 // src/sim_dynamics.cpp:36-41; r equation: src/sim_basic.cpp:469.
 inline void compute_tcs(const taylor_cfg &cfg, taylor_work &wk, const double st[7])
 {
+    if (cfg.dyn.kind & DYN_TAPE) {
+        tape_compute_tcs(cfg, wk, st);
+        return;
+    }
     const std::uint32_t p = wk.order;
     double *x = wk.c(0), *y = wk.c(1), *z = wk.c(2), *vx = wk.c(3), *vy = wk.c(4), *vz = wk.c(5), *r = wk.c(6);
     double *u = wk.u.data(), *w = wk.w.data();
@@ -1064,6 +1114,130 @@ inline double det_pow(double x, double y)
     return det_exp(y * det_log(x));
 }
 
+inline void tape_compute_tcs(const taylor_cfg &cfg, taylor_work &wk, const double st[7])
+{
+    const auto &d = cfg.dyn;
+    const std::uint32_t p = wk.order;
+    const std::size_t L = p + 1u;
+    wk.ws.assign(static_cast<std::size_t>(d.tape_nslots) * L, 0.);
+    double *ws = wk.ws.data();
+    for (int c = 0; c < 7; ++c) {
+        ws[static_cast<std::size_t>(c) * L] = st[c];
+    }
+    for (std::uint32_t n = 0; n < p; ++n) {
+        const double dn = static_cast<double>(n);
+        for (const auto &o : d.tape) {
+            const double *a = ws + static_cast<std::size_t>(o.a) * L;
+            double *r = ws + static_cast<std::size_t>(o.dst) * L;
+            const bool bs = o.b < 0;
+            const double sc = o.b == -1 ? o.c : ((o.b <= -2 && wk.pars) ? wk.pars[-2 - o.b] : 0.);
+            const double *b = bs ? nullptr : ws + static_cast<std::size_t>(o.b) * L;
+            switch (o.op) {
+                case TP_ADD:
+                    r[n] = bs ? (n == 0u ? a[0] + sc : a[n]) : a[n] + b[n];
+                    break;
+                case TP_SUB:
+                    r[n] = bs ? (n == 0u ? a[0] - sc : a[n]) : a[n] - b[n];
+                    break;
+                case TP_RSUB:
+                    r[n] = n == 0u ? sc - a[0] : -a[n];
+                    break;
+                case TP_MUL:
+                    r[n] = bs ? a[n] * sc : conv(a, b, n);
+                    break;
+                case TP_DIV:
+                    if (bs) {
+                        r[n] = a[n] / sc;
+                    } else {
+                        double acc = a[n];
+                        for (std::uint32_t j = 1; j <= n; ++j) {
+                            acc = std::fma(-b[j], r[n - j], acc);
+                        }
+                        r[n] = acc / b[0];
+                    }
+                    break;
+                case TP_RDIV: {
+                    double acc = n == 0u ? sc : 0.;
+                    for (std::uint32_t j = 1; j <= n; ++j) {
+                        acc = std::fma(-a[j], r[n - j], acc);
+                    }
+                    r[n] = acc / a[0];
+                    break;
+                }
+                case TP_SQR:
+                    r[n] = conv_sq(a, n);
+                    break;
+                case TP_POW:
+                    if (n == 0u) {
+                        r[0] = pow_order0(a[0], o.c);
+                    } else {
+                        double acc = 0;
+                        for (std::uint32_t j = 0; j < n; ++j) {
+                            const double cf = dn * o.c - static_cast<double>(j) * (o.c + 1.);
+                            acc = std::fma(cf * a[n - j], r[j], acc);
+                        }
+                        r[n] = acc / (dn * a[0]);
+                    }
+                    break;
+                case TP_SQRT:
+                    if (n == 0u) {
+                        r[0] = std::sqrt(a[0]);
+                    } else {
+                        double acc = a[n];
+                        for (std::uint32_t j = 1; j < n; ++j) {
+                            acc = std::fma(-r[j], r[n - j], acc);
+                        }
+                        r[n] = acc / (2. * r[0]);
+                    }
+                    break;
+                case TP_EXP:
+                    if (n == 0u) {
+                        r[0] = det_exp(a[0]);
+                    } else {
+                        double acc = 0;
+                        for (std::uint32_t j = 1; j <= n; ++j) {
+                            acc = std::fma(static_cast<double>(j) * a[j], r[n - j], acc);
+                        }
+                        r[n] = acc / dn;
+                    }
+                    break;
+                case TP_SINCOS: {
+                    double *sn = r, *cs = r + L;
+                    if (n == 0u) {
+                        sn[0] = std::sin(a[0]);
+                        cs[0] = std::cos(a[0]);
+                    } else {
+                        double as = 0, ac = 0;
+                        for (std::uint32_t j = 1; j <= n; ++j) {
+                            const double ja = static_cast<double>(j) * a[j];
+                            as = std::fma(ja, cs[n - j], as);
+                            ac = std::fma(ja, sn[n - j], ac);
+                        }
+                        sn[n] = as / dn;
+                        cs[n] = -(ac / dn);
+                    }
+                    break;
+                }
+                case TP_TIME:
+                    r[n] = n == 0u ? wk.time0 : (n == 1u ? 1. : 0.);
+                    break;
+                case TP_CONST:
+                    r[n] = n == 0u ? sc : 0.;
+                    break;
+                default:
+                    throw std::invalid_argument("Unknown operation in the dynamics tape");
+            }
+        }
+        const double f = wk.inv[n + 1u];
+        for (int c = 0; c < 7; ++c) {
+            ws[static_cast<std::size_t>(c) * L + n + 1u] = ws[static_cast<std::size_t>(d.tape_rhs[c]) * L + n] * f;
+        }
+    }
+    for (int c = 0; c < 7; ++c) {
+        std::copy(ws + static_cast<std::size_t>(c) * L, ws + static_cast<std::size_t>(c + 1) * L, wk.c(c));
+    }
+}
+
 // Jorba-Zou step-size rule as used by heyoka (EXTERNAL).
 // Returns NaN if any of the norms is non-finite.
 inline double rhofac(std::uint32_t p)
@@ -1169,6 +1343,7 @@ inline prop_result propagate_particle(const taylor_cfg &cfg, taylor_work &wk, co
         const dfloat rem = t_end - t;
         const double max_dt = rem.hi > 0 ? rem.hi : 0.;
 
+        wk.time0 = t.hi;
         compute_tcs(cfg, wk, st);
         double h = determine_h(wk);
         bool tlimit = false;

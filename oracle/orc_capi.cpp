@@ -240,6 +240,34 @@ int orc_sim_set_pars(void *h, const double *pars, std::uint64_t n, const double 
     });
 }
 
+// General dynamics as a tape (see orc::tape_op): switches the simulation to DYN_TAPE.
+int orc_sim_set_tape(void *h, const orc::tape_op *ops, std::uint64_t nops, std::uint32_t nslots, const std::int32_t *rhs7,
+                     std::uint32_t npars)
+{
+    return guarded([&]() {
+        auto &d = S(h)->prm.tcfg.dyn;
+        for (std::uint64_t k = 0; k < nops; ++k) {
+            const auto &o = ops[k];
+            const bool two = o.op == orc::TP_SINCOS;
+            if (o.op < orc::TP_ADD || o.op > orc::TP_CONST || o.dst < 7 || static_cast<std::uint32_t>(o.dst) + (two ? 1u : 0u) >= nslots
+                || o.a < 0 || o.a >= o.dst || o.b >= o.dst || (o.b <= -2 && static_cast<std::uint32_t>(-2 - o.b) >= npars)) {
+                throw std::invalid_argument("Malformed dynamics tape");
+            }
+        }
+        d.tape.assign(ops, ops + nops);
+        d.tape_nslots = nslots;
+        d.tape_npars = npars;
+        for (int c = 0; c < 7; ++c) {
+            if (rhs7[c] < 0 || static_cast<std::uint32_t>(rhs7[c]) >= nslots) {
+                throw std::invalid_argument("Malformed dynamics tape");
+            }
+            d.tape_rhs[c] = rhs7[c];
+        }
+        d.kind = orc::DYN_TAPE;
+        return 0;
+    });
+}
+
 void orc_sim_free(void *h)
 {
     delete S(h);

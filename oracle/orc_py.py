@@ -96,6 +96,8 @@ def lib():
         L.orc_broad_phase_brute.argtypes = [u64, vp, vp, vp, vp, vp, u64]
         L.orc_sim_set_pars.restype = i32
         L.orc_sim_set_pars.argtypes = [vp, vp, u64, vp]
+        L.orc_sim_set_tape.restype = i32
+        L.orc_sim_set_tape.argtypes = [vp, vp, u64, C.c_uint32, vp, C.c_uint32]
         L.orc_sim_new.restype = vp
         L.orc_sim_new.argtypes = [vp, u64, dbl, u32, dbl, dbl, dbl, i32, dbl, dbl, dbl, dbl, i32, vp]
         L.orc_sim_free.argtypes = [vp]
@@ -176,6 +178,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+TAPE_DTYPE = np.dtype([("op", "<i4"), ("dst", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<f8")])
+
+
 class OracleError(ValueError):
     pass
 
@@ -201,6 +206,7 @@ class Sim:
         conj_whitelist=(),
         pars=None,
         dens=None,
+        tape=None,
     ):
         L = lib()
         st = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(-1, 7))
@@ -216,6 +222,13 @@ class Sim:
         if not self._h:
             raise OracleError(L.orc_last_error().decode())
         self._L = L
+        if tape is not None:
+            # General dynamics: tape = {"ops": structured array (op, dst, a, b, c), "nslots", "rhs" [7],
+            # "npars"} as produced by cascade_amd.core.lower_dynamics (the dynamics definition).
+            ops = np.ascontiguousarray(tape["ops"], dtype=TAPE_DTYPE)
+            rhs = np.ascontiguousarray(tape["rhs"], dtype=np.int32)
+            if L.orc_sim_set_tape(self._h, _p(ops), len(ops), int(tape["nslots"]), _p(rhs), int(tape["npars"])) != 0:
+                raise OracleError(L.orc_last_error().decode())
         if pars is not None:
             # dyn_kind bit 1 (drag): pars[:, 0] = BSTAR; dens = the 12 density-fit constants or None
             pr = np.ascontiguousarray(np.asarray(pars, dtype=np.float64).reshape(-1))

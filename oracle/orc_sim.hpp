@@ -217,7 +217,9 @@ public:
                                                           && (coll_wl_empty || m_coll_whitelist.count(pidx) == 1u));
                     conj_active[pidx]
                         = static_cast<char>(with_conj && (conj_wl_empty || m_conj_whitelist.count(pidx) == 1u));
-                    wk.par0 = (prm.tcfg.dyn.npars() != 0u && pidx < prm.pars.size()) ? prm.pars[pidx] : 0.;
+                    const std::uint32_t npars = prm.tcfg.dyn.npars();
+                    wk.pars = (npars != 0u && (pidx + 1u) * npars <= prm.pars.size()) ? &prm.pars[pidx * npars] : nullptr;
+                    wk.par0 = wk.pars ? wk.pars[0] : 0.;
                     const auto res = propagate_particle(prm.tcfg, wk, &m_state[pidx * 7u], init_time, delta_t0,
                                                         s_data[pidx], &final_state[pidx * 6u]);
                     if (res.status == 2) {
