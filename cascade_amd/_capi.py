@@ -47,6 +47,10 @@ class PropCfg(C.Structure):
         ("dens_gamma", C.c_double * 4),
         ("d_pars", C.c_void_p),
         ("npars", C.c_uint32),
+        ("tape", C.c_void_p),
+        ("tape_nops", C.c_uint32),
+        ("tape_nslots", C.c_uint32),
+        ("tape_rhs", C.c_int32 * 7),
     ]
 
 
@@ -61,6 +65,7 @@ class PropSummary(C.Structure):
         ("ste_ev_idx", C.c_uint32),
         ("ste_time", C.c_double),
         ("total_substeps", C.c_uint64),
+        ("max_substeps", C.c_uint32),
     ]
 
 
@@ -99,6 +104,7 @@ SYMBOLS = {
     "csc_profile_reset": (_i32, [_vp]),
     "csc_profile_get": (_i32, [_vp, C.c_char_p, _sz]),
     "csc_propagate": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 10),
+    "csc_propagate_rows": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 10 + [_u32] + [_vp] * 4),
     "csc_propagate_summary": (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(PropSummary)]),
     "csc_exclusive_scan": (_i32, [_vp, _vp, _u64, _vp]),
     "csc_tc_strides": (_i32, [_u32, C.POINTER(_u32), C.POINTER(_u32)]),

@@ -191,6 +191,7 @@ struct sum_partial {
     uint32_t ste_idx, ste_ev;
     double ste_time;
     uint64_t nsub;
+    uint32_t max_nsub, pad;
 };
 
 constexpr int SUM_BLOCK = 256;
@@ -210,10 +211,13 @@ __global__ __launch_bounds__(SUM_BLOCK) void k_prop_summary(uint32_t n, const ui
     p.ste_ev = 0;
     p.ste_time = 0;
     p.nsub = 0;
+    p.max_nsub = 0;
+    p.pad = 0;
     for (uint32_t i = blockIdx.x * SUM_BLOCK + threadIdx.x; i < n; i += gridDim.x * SUM_BLOCK) {
         const int32_t st = status[i];
         p.flags |= static_cast<uint32_t>(st) & 0xffffff00u;
         p.nsub += nsub[i];
+        p.max_nsub = p.max_nsub > nsub[i] ? p.max_nsub : nsub[i];
         const int code = st & 0xff;
         if (code == csc::ST_NF) {
             const double t = nf_last_t[i];
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(SUM_BLOCK) void k_prop_summary(uint32_t n, const ui
             const sum_partial &o = sh[k];
             p.flags |= o.flags;
             p.nsub += o.nsub;
+            p.max_nsub = p.max_nsub > o.max_nsub ? p.max_nsub : o.max_nsub;
             if (o.n_nf) {
                 if (p.n_nf == 0 || o.nf_time < p.nf_time || (o.nf_time == p.nf_time && o.nf_idx < p.nf_idx)) {
                     p.nf_time = o.nf_time;
@@ -257,6 +262,29 @@ __global__ __launch_bounds__(SUM_BLOCK) void k_prop_summary(uint32_t n, const ui
         }
         out[blockIdx.x] = p;
     }
+}
+
+// Conjunction records -> sortable keys: the bit pattern of the (absolute) time, mapped so that
+// unsigned order = numeric order.
+__global__ __launch_bounds__(256) void k_conj_keys(uint32_t n, const csc::conj_rec *c, uint64_t *keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(c[i].time));
+    keys[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// dst[k] = src[idx[k]] for 128-byte records, 8 lanes per record (one 16-byte piece each).
+__global__ __launch_bounds__(256) void k_conj_gather(uint32_t n, const uint4 *src, const uint32_t *idx, uint4 *dst)
+{
+    const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t rec = t >> 3;
+    if (rec >= n) {
+        return;
+    }
+    dst[t] = src[static_cast<uint64_t>(idx[rec]) * 8u + (t & 7u)];
 }
 
 __global__ __launch_bounds__(256) void k_copy_final_state(uint32_t n, const double *fs, double *state)
@@ -339,6 +367,7 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
     }
     p.pars = cfg->d_pars;
     p.npars = cfg->npars;
+    p.row_cap = 0;
     p.tape = nullptr;
     p.tape_nops = p.tape_nslots = 0;
     p.tape_ws = nullptr;
@@ -635,9 +664,10 @@ int csc_check_flags(csc_ctx *ctx)
 
 // ---- K1 / K2 ---------------------------------------------------------------------------
 
-int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
-                  int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
-                  double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs)
+static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
+                          int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
+                          double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,
+                          uint64_t *d_tc_row, double *d_tcs_xyz, double *d_tcs_vr, double *d_tcoords)
 {
     if (const int rc = check_cfg(ctx, cfg)) {
         return rc;
@@ -655,6 +685,11 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
     p.lbs = d_lbs;
     p.ubs = d_ubs;
     p.recs = d_recs;
+    p.row_cap = row_cap;
+    p.tc_row = d_tc_row;
+    p.tcs_xyz = d_tcs_xyz;
+    p.tcs_vr = d_tcs_vr;
+    p.tcoords = d_tcoords;
     const bool events = cfg->has_exit || cfg->has_reentry;
     dim3 grid(cdiv(n, 64)), block(64);
     if (cfg->dyn_kind == CSC_DYN_TAPE) {
@@ -662,9 +697,29 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
             return rc;
         }
     }
-    KT("k_propagate", launch_propagate<false>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
+    KT(row_cap ? "k_propagate_rows" : "k_propagate", launch_propagate<false>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
+}
+
+int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
+                  int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
+                  double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs)
+{
+    return propagate_impl(ctx, cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, d_lbs,
+                          d_ubs, d_recs, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+int csc_propagate_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
+                       int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
+                       double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,
+                       uint64_t *d_tc_row, double *d_tcs_xyz, double *d_tcs_vr, double *d_tcoords)
+{
+    if (row_cap == 0u || !d_tc_row || !d_tcs_xyz || !d_tcs_vr || !d_tcoords) {
+        return ctx->invalid("csc_propagate_rows needs a row capacity and the row arrays");
+    }
+    return propagate_impl(ctx, cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, d_lbs,
+                          d_ubs, d_recs, row_cap, d_tc_row, d_tcs_xyz, d_tcs_vr, d_tcoords);
 }
 
 int csc_tc_strides(uint32_t order, uint32_t *xyz_stride, uint32_t *vr_stride)
@@ -725,6 +780,7 @@ int csc_propagate_summary(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, cons
     for (const auto &o : h) {
         s.flags |= o.flags;
         s.total_substeps += o.nsub;
+        s.max_substeps = std::max(s.max_substeps, o.max_nsub);
         if (o.n_nf) {
             if (s.n_nf == 0 || o.nf_time < s.nf_time || (o.nf_time == s.nf_time && o.nf_idx < s.nf_idx)) {
                 s.nf_time = o.nf_time;
@@ -1203,7 +1259,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             src.npairs, std::max<size_t>(ctx->bufs["np_cand"].cap / sizeof(uint4), 262144)));
     }
     uint32_t h[8];
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    // The lists feed each other (candidates -> survivors / deferred -> events), so an overflow
+    // upstream hides the true size downstream: up to one retry per list, plus slack.
+    for (int attempt = 0; attempt < 8; ++attempt) {
         CSC_BUF(d_coll, csc::coll_rec, "np_coll", coll_cap);
         CSC_BUF(d_conj, csc::conj_rec, "np_conj", conj_cap);
         CSC_BUF(d_surv, uint4, "np_surv", static_cast<size_t>(surv_cap) * 2u);
@@ -1275,7 +1333,28 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                 CSC_HIP(hipMemcpyAsync(ctx->coll.data(), d_coll, h[0] * sizeof(csc::coll_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
             }
-            if (h[1]) {
+            // Large conjunction lists are put in time order on the device (radix sort of the time
+            // keys, gather of the 128-byte records); ties and small lists are ordered on the host.
+            const bool dev_sorted = h[1] > 32768u;
+            if (dev_sorted) {
+                const uint32_t nc = h[1];
+                CSC_BUF(d_ka, uint64_t, "conj_keys_a", nc);
+                CSC_BUF(d_kb, uint64_t, "conj_keys_b", nc);
+                CSC_BUF(d_va, uint32_t, "conj_vals_a", nc);
+                CSC_BUF(d_vb, uint32_t, "conj_vals_b", nc);
+                CSC_BUF(d_sorted, csc::conj_rec, "np_conj_sorted", nc);
+                KT("k_conj_keys", hipLaunchKernelGGL(k_conj_keys, dim3(cdiv(nc, 256)), dim3(256), 0, ctx->stream, nc, d_conj, d_ka));
+                uint64_t *kres;
+                uint32_t *vres;
+                if (const int rc = radix_sort(ctx, nc, 1, 64, d_ka, d_va, true, d_kb, d_vb, &kres, &vres)) {
+                    return rc;
+                }
+                KT("k_conj_gather", hipLaunchKernelGGL(k_conj_gather, dim3(cdiv(static_cast<uint64_t>(nc) * 8u, 256)), dim3(256), 0,
+                                                        ctx->stream, nc, reinterpret_cast<const uint4 *>(d_conj), vres,
+                                                        reinterpret_cast<uint4 *>(d_sorted)));
+                CSC_LAUNCH_CHECK();
+                CSC_HIP(hipMemcpyAsync(ctx->conj.data(), d_sorted, nc * sizeof(csc::conj_rec), hipMemcpyDeviceToHost, ctx->stream));
+            } else if (h[1]) {
                 CSC_HIP(hipMemcpyAsync(ctx->conj.data(), d_conj, h[1] * sizeof(csc::conj_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
             }
@@ -1284,9 +1363,24 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             std::sort(ctx->coll.begin(), ctx->coll.end(), [](const csc_collision &a, const csc_collision &b) {
                 return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
             });
-            std::sort(ctx->conj.begin(), ctx->conj.end(), [](const csc_conjunction &a, const csc_conjunction &b) {
+            const auto conj_less = [](const csc_conjunction &a, const csc_conjunction &b) {
                 return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
-            });
+            };
+            if (dev_sorted) {
+                // Already in time order: only runs of equal times need (i, j) order.
+                for (size_t b0 = 0; b0 < ctx->conj.size();) {
+                    size_t e0 = b0 + 1;
+                    while (e0 < ctx->conj.size() && ctx->conj[e0].time == ctx->conj[b0].time) {
+                        ++e0;
+                    }
+                    if (e0 - b0 > 1) {
+                        std::sort(ctx->conj.begin() + static_cast<std::ptrdiff_t>(b0), ctx->conj.begin() + static_cast<std::ptrdiff_t>(e0), conj_less);
+                    }
+                    b0 = e0;
+                }
+            } else {
+                std::sort(ctx->conj.begin(), ctx->conj.end(), conj_less);
+            }
             *n_coll = h[0];
             *n_conj = h[1];
             if (warn_flags) {
@@ -1295,10 +1389,17 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             return CSC_OK;
         }
         // Output overflow: grow and run again (results are recomputed from scratch).
-        coll_cap = std::max(coll_cap, h[0] + h[0] / 4u + 16u);
-        conj_cap = std::max(conj_cap, h[1] + h[1] / 4u + 16u);
-        surv_cap = std::max(surv_cap, h[3] + h[3] / 4u + 16u);
-        defer_cap = std::max(defer_cap, h[4] + h[4] / 4u + 16u);
+        // When the candidate list overflowed, the downstream counts are those of the truncated
+        // list: scale them by the same factor.
+        const double up = h[5] > cand_cap ? static_cast<double>(h[5]) / cand_cap : 1.;
+        auto grow = [up](uint32_t cap, uint32_t seen) {
+            const double want = static_cast<double>(seen) * up * 1.25 + 16.;
+            return std::max(cap, static_cast<uint32_t>(std::min(want, 4.0e9)));
+        };
+        coll_cap = grow(coll_cap, h[0]);
+        conj_cap = grow(conj_cap, h[1]);
+        surv_cap = grow(surv_cap, h[3]);
+        defer_cap = grow(defer_cap, h[4]);
         cand_cap = std::max(cand_cap, h[5] + h[5] / 4u + 16u);
     }
     ctx->err = "narrow phase output overflow";

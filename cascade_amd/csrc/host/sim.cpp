@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <charconv>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -318,6 +319,12 @@ struct sim::sim_data {
     int device = 0;
     dfloat time;
     bool host_sync = true, np_prefilter = true;
+    // Dense-output rows in one pass: 0 never, 1 for everything but plain Kepler (default), 2 always
+    // (environment CASCADE_SINGLE_PASS, for measurements); row_hint = most substeps of one particle
+    // in the previous superstep (valid for the same ct and n_par_ct).
+    int single_pass_mode = 2;
+    std::uint32_t row_hint = 0, row_hint_nchunks = 0;
+    double row_hint_ct = 0;
     std::uint32_t shard_rank = 0, shard_n = 1;
     exchange_t exchange;
     step_stats stats;
@@ -336,6 +343,7 @@ struct sim::sim_data {
     sim_data(const sim_data &o)
         : dyn(o.dyn), tape(o.tape), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
+          single_pass_mode(o.single_pass_mode),
           shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange)
     {
     }
@@ -531,6 +539,9 @@ void sim::finalise_ctor(options o)
     m_data->high_accuracy = o.high_accuracy;
     m_data->compact_mode = o.compact_mode;
     m_data->device = o.device;
+    if (const char *e = std::getenv("CASCADE_SINGLE_PASS")) {
+        m_data->single_pass_mode = std::atoi(e);
+    }
 
     verify_state_vector(*m_state);
 }
@@ -848,12 +859,17 @@ void sim::download_state()
 void sim::append_conj_data(const void *recs, std::size_t n)
 {
     static_assert(sizeof(conjunction) == sizeof(csc_conjunction), "conjunction layout");
-    auto nv = std::make_shared<std::vector<conjunction>>();
-    nv->reserve(m_det_conj->size() + n);
-    nv->insert(nv->end(), m_det_conj->begin(), m_det_conj->end());
+    // src/sim_narrow_phase.cpp:999-1011: when the vector cannot take the new records, a NEW one
+    // with twice the needed capacity replaces it (arrays handed out earlier keep the old one
+    // alive); otherwise the records are appended in place.
+    if (m_det_conj->size() + n > m_det_conj->capacity()) {
+        auto nv = std::make_shared<std::vector<conjunction>>();
+        nv->reserve(2u * (m_det_conj->size() + n));
+        nv->insert(nv->end(), m_det_conj->begin(), m_det_conj->end());
+        m_det_conj = std::move(nv);
+    }
     const auto *src = static_cast<const conjunction *>(recs);
-    nv->insert(nv->end(), src, src + n);
-    m_det_conj = std::move(nv);
+    m_det_conj->insert(m_det_conj->end(), src, src + n);
 }
 
 // dense_propagate (src/sim_propagate.cpp:1386-1503) + copy_from_final_state.
@@ -993,9 +1009,40 @@ outcome sim::step()
         cfg.reentry_c0 = r * r;
     }
 
-    d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
+    // Dense-output rows (the propagate callback, :710-755). Plain Kepler is cheap enough to be
+    // integrated twice: pass 1 for the boxes, pass 2 (after the sort) writes exact-fit rows in
+    // Morton order. Every other right-hand side is integrated ONCE, writing its rows on the way
+    // into fixed slots of row_cap rows per particle, row_cap following the previous superstep; a
+    // particle that needs more falls back on the second pass for this superstep.
+    std::uint32_t xs = 0, vs = 0;
+    d.chk(csc_tc_strides(d.order, &xs, &vs));
+    if (d.row_hint_ct != m_ct || d.row_hint_nchunks != nchunks0) {
+        d.row_hint = 0;
+    }
+    std::uint32_t row_cap = 0;
+    if (d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler) && d.row_hint != 0u) {
+        row_cap = d.row_hint + std::max(2u, d.row_hint / 4u);
+        if (static_cast<double>(n) * row_cap * (xs + vs + 2u) * 8. > 96e9) {
+            row_cap = 0; // would not fit comfortably: two passes
+        }
+    }
+    double *d_txyz = nullptr, *d_tvr = nullptr, *d_tco = nullptr;
+    if (row_cap != 0u) {
+        const std::uint64_t rows = static_cast<std::uint64_t>(n) * row_cap;
+        d_txyz = d.buf<double>("tcs_xyz", rows * xs);
+        d_tvr = d.buf<double>("tcs_vr", rows * vs);
+        d_tco = d.buf<double>("tcoords", rows * 2u);
+        d.chk(csc_propagate_rows(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
+                                 d_recs, row_cap, d_tc_row, d_txyz, d_tvr, d_tco));
+    } else {
+        d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
+    }
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+    d.row_hint = summ.max_substeps;
+    d.row_hint_ct = m_ct;
+    d.row_hint_nchunks = nchunks0;
+    const bool rows_done = row_cap != 0u && !(summ.flags & CSC_ST_FLAG_ROW_OVERFLOW);
 
     if (summ.n_nf) {
         // :1127-1145: nothing user-visible changes.
@@ -1031,14 +1078,14 @@ outcome sim::step()
     d.chk(csc_morton_encode(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes));
     d.chk(csc_sort_gather(ctx, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs));
 
-    // Taylor coefficients for dense output: CSR rows in the Morton order of chunk 0.
+    // Taylor coefficients for dense output, two-pass mode: CSR rows in the Morton order of chunk 0.
     const std::uint64_t tot = summ.total_substeps;
-    std::uint32_t xs = 0, vs = 0;
-    d.chk(csc_tc_strides(d.order, &xs, &vs));
-    auto *d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(tot, 1) * xs);
-    auto *d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(tot, 1) * vs);
-    auto *d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
-    d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
+    if (!rows_done) {
+        d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(tot, 1) * xs);
+        d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(tot, 1) * vs);
+        d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
+        d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
+    }
     d.chk(csc_bvh_build(ctx, n, nchunks, d_scodes, d_slbs, d_subs));
     std::uint64_t npairs = 0;
     d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));

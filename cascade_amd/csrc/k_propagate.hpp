@@ -62,6 +62,7 @@ enum : int {
     ST_FLAG_BAD_TCOORD = 0x200, // non-finite time coordinate (:726-730)
     ST_FLAG_MAX_SUBSTEPS = 0x400,
     ST_FLAG_RF_WARN = 0x800,
+    ST_FLAG_ROW_OVERFLOW = 0x1000, // single-pass mode: more substeps than row_cap
 };
 
 struct prop_params {
@@ -101,6 +102,10 @@ struct prop_params {
     double *final_state; // [N][6]
     float *lbs, *ubs;    // [C][N][4]
     float *recs;         // [C][N][16] sampled-trajectory records for the narrow-phase pre-filter (may be null)
+    // Single-pass mode (row_cap > 0, pass 1 only): the Taylor rows are written during the
+    // integration into the fixed slots [i * row_cap, (i + 1) * row_cap) of particle i
+    // (tcs_xyz / tcs_vr / tcoords / tc_row below), and there is no second pass.
+    std::uint32_t row_cap;
     // pass 2
     const std::uint32_t *order;     // [N] particle handled by lane k (null = identity)
     const std::uint64_t *row_base;  // [N] first CSR row of lane k
@@ -668,7 +673,32 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
     if constexpr (STORE) {
         row = prm.row_base[lane_k];
         prm.tc_row[i] = row;
+    } else {
+        if (prm.row_cap != 0u) {
+            row = static_cast<std::size_t>(i) * prm.row_cap;
+            prm.tc_row[i] = row;
+        }
     }
+    // One dense-output row: the callback of src/sim_propagate.cpp:710-755.
+    auto write_row = [&](std::size_t r, const dfl &tc) {
+        constexpr int XS = tc_xyz_stride(P), VS = tc_vr_stride(P);
+        double2 *dxyz = reinterpret_cast<double2 *>(prm.tcs_xyz + r * static_cast<std::size_t>(XS));
+        const double *axyz[3] = {t.x, t.y, t.z};
+#pragma unroll
+        for (int e = 0; e < XS; e += 2) {
+            const double v0 = axyz[e / (P + 1)][e % (P + 1)];
+            const double v1 = (e + 1 < 3 * (P + 1)) ? axyz[(e + 1) / (P + 1)][(e + 1) % (P + 1)] : 0.;
+            dxyz[e / 2] = make_double2(v0, v1);
+        }
+        double2 *dvr = reinterpret_cast<double2 *>(prm.tcs_vr + r * static_cast<std::size_t>(VS));
+        const double *avr[4] = {t.vx, t.vy, t.vz, t.r};
+#pragma unroll
+        for (int e = 0; e < VS; e += 2) {
+            dvr[e / 2] = make_double2(avr[e / (P + 1)][e % (P + 1)], avr[(e + 1) / (P + 1)][(e + 1) % (P + 1)]);
+        }
+        prm.tcoords[r * 2u] = tc.hi;
+        prm.tcoords[r * 2u + 1u] = tc.lo;
+    };
 
     while (true) {
         const dfl rem = df_sub(t_end, tm);
@@ -772,24 +802,16 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                 flags |= ST_FLAG_BAD_TCOORD;
             }
             if constexpr (STORE) {
-                constexpr int XS = tc_xyz_stride(P), VS = tc_vr_stride(P);
-                double2 *dxyz = reinterpret_cast<double2 *>(prm.tcs_xyz + (row + ns) * static_cast<std::size_t>(XS));
-                const double *axyz[3] = {t.x, t.y, t.z};
-#pragma unroll
-                for (int e = 0; e < XS; e += 2) {
-                    const double v0 = axyz[e / (P + 1)][e % (P + 1)];
-                    const double v1 = (e + 1 < 3 * (P + 1)) ? axyz[(e + 1) / (P + 1)][(e + 1) % (P + 1)] : 0.;
-                    dxyz[e / 2] = make_double2(v0, v1);
+                write_row(row + ns, tc);
+            }
+            if constexpr (!STORE) {
+                if (prm.row_cap != 0u) {
+                    if (ns < prm.row_cap) {
+                        write_row(row + ns, tc);
+                    } else {
+                        flags |= ST_FLAG_ROW_OVERFLOW;
+                    }
                 }
-                double2 *dvr = reinterpret_cast<double2 *>(prm.tcs_vr + (row + ns) * static_cast<std::size_t>(VS));
-                const double *avr[4] = {t.vx, t.vy, t.vz, t.r};
-#pragma unroll
-                for (int e = 0; e < VS; e += 2) {
-                    dvr[e / 2] = make_double2(avr[e / (P + 1)][e % (P + 1)], avr[(e + 1) / (P + 1)][(e + 1) % (P + 1)]);
-                }
-                prm.tcoords[(row + ns) * 2u] = tc.hi;
-                prm.tcoords[(row + ns) * 2u + 1u] = tc.lo;
-            } else {
                 // Fused compute_particle_aabb (:217-395): chunks k with cb_k < tc and ce_k > tc_prev.
                 while (kc < C) {
                     const double ce = (kc == C - 1u) ? prm.delta_t : prm.ct * static_cast<double>(kc + 1u);

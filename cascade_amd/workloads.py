@@ -60,16 +60,34 @@ def random_leo_pop_kep(nparts=17378, seed=42):
     return st
 
 
-def leo_si_population(n, seed=42, with_bstar=True):
-    """Synthetic LEO population in SI units for the perturbed dynamics (J2 / drag): near-circular
-    orbits, altitude 250-1200 km, all inclinations, sizes 0.1-5 m, BSTAR log-uniform in
-    [1e-5, 1e-3] (SI form of simple_earth: acceleration = rho / rho_ref * BSTAR * |v| v).
-    Returns (state [n, 7], pars [n, 1])."""
+# Quantiles (0, 1, 5, 10, 25, 50, 75, 90, 95, 99, 100 %) of the reference's 19 647-object catalogue
+# benchmark/data/test_ic_19647.txt / test_par_19647.txt (semi-major axis altitude, eccentricity,
+# inclination, BSTAR in the SI form of simple_earth, radius): summary statistics only, the
+# catalogue itself is not shipped.
+_Q = np.array([0, 1, 5, 10, 25, 50, 75, 90, 95, 99, 100]) / 100.0
+_Q_ALT_KM = np.array([152.96, 339.20, 446.75, 492.87, 564.23, 790.30, 980.99, 1414.44, 1532.13, 2172.11, 3621.33])
+_Q_ECC = np.array([8.44e-06, 3.22e-04, 6.54e-04, 9.22e-04, 1.62e-03, 4.17e-03, 1.13e-02, 2.62e-02, 5.35e-02, 1.70e-01, 3.42e-01])
+_Q_INC_DEG = np.array([0.05, 31.0, 52.02, 53.06, 73.88, 83.21, 98.62, 99.23, 100.15, 102.39, 144.64])
+_Q_BSTAR = np.array([0.0, 0.0, 0.0, 9.79e-13, 1.29e-11, 4.65e-11, 1.40e-10, 3.10e-10, 5.58e-10, 3.04e-09, 1.56e-07])
+_Q_SIZE = np.array([5.64e-03, 2.39e-02, 4.26e-02, 5.29e-02, 6.91e-02, 0.15, 0.689, 2.0, 2.0, 2.0, 11.27])
+
+
+def leo_si_population(n, seed=42, with_bstar=True, min_perigee_km=200.0):
+    """Synthetic LEO catalogue in SI units shaped like the reference's 2022 population
+    (benchmark/data/test_ic_19647.txt, BASELINE configs[2]): semi-major axis, eccentricity,
+    inclination, BSTAR and radius are resampled independently from the catalogue's quantiles
+    (inverse-CDF interpolation), angles are uniform; eccentricities are capped so that every
+    perigee stays above min_perigee_km (the reference's driver removes objects below the reentry
+    radius Re + 150 km before it starts). Returns (state [n, 7], pars [n, 1])."""
     rng = np.random.default_rng(seed)
     GM, Re = 3.986004407799724e14, 6378136.3
-    a = Re + rng.uniform(250e3, 1200e3, n)
-    e = rng.uniform(0.0, 0.01, n)
-    inc = np.arccos(rng.uniform(-1.0, 1.0, n))
+
+    def draw(table):
+        return np.interp(rng.uniform(0.0, 1.0, n), _Q, table)
+
+    a = Re + 1e3 * np.maximum(draw(_Q_ALT_KM), min_perigee_km + 20.0)
+    e = np.minimum(draw(_Q_ECC), 1.0 - (Re + 1e3 * min_perigee_km) / a)
+    inc = np.deg2rad(draw(_Q_INC_DEG))
     Om, om, nu = (rng.uniform(0, 2 * np.pi, n) for _ in range(3))
     p = a * (1 - e * e)
     r = p / (1 + e * np.cos(nu))
@@ -84,9 +102,9 @@ def leo_si_population(n, seed=42, with_bstar=True):
     vx = vr * x / r - vt * (cO * su + sO * cu * ci)
     vy = vr * y / r - vt * (sO * su - cO * cu * ci)
     vz = vr * z / r + vt * si * cu
-    size = rng.uniform(0.1, 5.0, n)
+    size = draw(_Q_SIZE)
     st = np.stack([x, y, z, vx, vy, vz, size], axis=1)
-    pars = np.exp(rng.uniform(np.log(1e-5), np.log(1e-3), n)).reshape(n, 1) if with_bstar else np.zeros((n, 0))
+    pars = draw(_Q_BSTAR).reshape(n, 1) if with_bstar else np.zeros((n, 0))
     return np.ascontiguousarray(st), np.ascontiguousarray(pars)
 
 

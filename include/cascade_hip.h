@@ -118,7 +118,8 @@ enum {
     CSC_ST_NF = 2,
     CSC_ST_FLAG_BAD_AABB = 0x100,
     CSC_ST_FLAG_BAD_TCOORD = 0x200,
-    CSC_ST_FLAG_MAX_SUBSTEPS = 0x400
+    CSC_ST_FLAG_MAX_SUBSTEPS = 0x400,
+    CSC_ST_FLAG_ROW_OVERFLOW = 0x1000 /* csc_propagate_rows: a particle took more than row_cap substeps */
 };
 
 /* Summary of a propagation pass (host struct filled by csc_propagate_summary). */
@@ -132,6 +133,7 @@ typedef struct csc_prop_summary {
     uint32_t ste_ev_idx;
     double ste_time;
     uint64_t total_substeps;
+    uint32_t max_substeps; /* most substeps taken by one particle */
 } csc_prop_summary;
 
 /* Collision record (the tuple of sim_data::coll_vec, sim_data.hpp:304) and conjunction record
@@ -193,6 +195,19 @@ int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap);
 int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                   int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
                   double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs);
+
+/* Single-pass variant of csc_propagate + csc_propagate_store for dynamics whose integration is
+ * too expensive to repeat (everything but plain Kepler): the propagate callback
+ * (src/sim_propagate.cpp:710-755) writes the Taylor rows during the integration, as the reference
+ * does, into fixed slots: particle i owns rows [i * row_cap, (i + 1) * row_cap) of d_tcs_xyz /
+ * d_tcs_vr / d_tcoords (layouts as for csc_propagate_store, each array sized n * row_cap rows) and
+ * d_tc_row[i] = i * row_cap. A particle that takes more than row_cap substeps sets
+ * CSC_ST_FLAG_ROW_OVERFLOW in its status (csc_prop_summary.flags); the rows are then incomplete
+ * and the caller falls back on csc_propagate_store. Asynchronous. */
+int csc_propagate_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
+                       int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
+                       double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,
+                       uint64_t *d_tc_row, double *d_tcs_xyz, double *d_tcs_vr, double *d_tcoords);
 
 /* Reductions over the per-particle records (earliest nf state / terminal event, flags,
  * total substeps): src/sim_propagate.cpp:1127-1153. Synchronises; fills *out on the host. */

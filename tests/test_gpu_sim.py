@@ -303,3 +303,43 @@ def test_drag_decays_and_reenters():
     oc = s.propagate_until(86400.0 * 2)
     assert oc == outcome.reentry and s.interrupt_info == 0
     assert abs(np.linalg.norm(s.state[0, :3]) - (Re + 150e3)) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["j2drag", "tape"])
+def test_single_pass_rows_change_nothing(kind, monkeypatch):
+    """Dynamics other than plain Kepler write their dense-output rows during the one integration
+    (csc_propagate_rows) instead of re-integrating in a second pass: every event and state must be
+    bit-identical with the two-pass path, including a superstep whose row capacity overflows."""
+    from cascade_amd import _capi, dynamics, sim
+    from cascade_amd.workloads import leo_si_population
+
+    st, pars = leo_si_population(6000, seed=12)
+    st[:, 6] *= 200.0
+    dyn = dynamics.simple_earth(C22S22=(kind == "tape"))
+    kw = dict(dyn=dyn, pars=pars, n_par_ct=4, conj_thresh=20e3, reentry_radius=6378136.3 + 150e3)
+    monkeypatch.setenv("CASCADE_SINGLE_PASS", "0")
+    a = sim(st.copy(), 185.5663, **kw)
+    monkeypatch.setenv("CASCADE_SINGLE_PASS", "1")
+    b = sim(st.copy(), 185.5663, **kw)
+    ctx = _capi.Context.from_handle(b._hip_context)
+    ctx.profile(True)
+    n_events = 0
+    for k in range(5):
+        if k == 3:
+            # Longer chunks at the same n_par_ct would keep the hint; a new n_par_ct drops it,
+            # and the larger superstep after that exercises hint -> capacity again.
+            a.n_par_ct = b.n_par_ct = 9
+        oa, ob = a.step(), b.step()
+        assert oa == ob and a.interrupt_info == b.interrupt_info
+        assert a.last_collisions.tobytes() == b.last_collisions.tobytes()
+        assert a.last_step_conjunctions.tobytes() == b.last_step_conjunctions.tobytes()
+        assert np.array_equal(a.state, b.state) and a.time == b.time
+        n_events += len(a.last_collisions) + len(a.last_step_conjunctions)
+        if oa.name in ("reentry", "collision"):
+            ii = a.interrupt_info
+            for s in (a, b):
+                s.remove_particles([ii] if isinstance(ii, int) else list(ii))
+    prof = ctx.profile_get()
+    assert prof["k_propagate_rows"][0] >= 2, prof.keys()
+    assert n_events > 0
