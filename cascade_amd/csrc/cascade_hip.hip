@@ -21,6 +21,7 @@
 
 #include "dev_math.hpp"
 #include "k_bvh.hpp"
+#include "k_bp_dual.hpp"
 #include "k_morton.hpp"
 #include "k_narrow.hpp"
 #include "k_propagate.hpp"
@@ -57,6 +58,14 @@ struct csc_ctx {
     const uint32_t *bp_vidx = nullptr; // the permutation the pair positions refer to
     uint32_t bp_n = 0, bp_chunks = 0;
     uint32_t shard_rank = 0, shard_n = 1; // query sharding of the broad phase (csc_set_shard)
+    // dual traversal (k_bp_dual.hpp): flat pair lists of the last broad phase, capacities that
+    // follow the last superstep
+    bool bp_flat = false;
+    const unsigned long long *bp_flat_pairs = nullptr;
+    uint32_t bp_flat_cap = 0;
+    uint32_t bp_flat_cnt[csc::DT_SHARDS] = {};
+    uint32_t dt_fr_cap = 0, dt_pair_cap = 0;
+    int bp_mode = -1; // -1: read CASCADE_BP_MODE once; 0 per-particle walks, 1 dual traversal
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
@@ -1028,6 +1037,119 @@ int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
     return CSC_OK;
 }
 
+// Dual traversal (k_bp_dual.hpp): one launch per level of the pair tree, the frontier sizes stay
+// on the device; the host looks at them every few levels to stop.
+static_assert(csc::NP_FLAT_SHARDS == csc::DT_SHARDS, "flat pair lists");
+static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                            const uint32_t *d_vidx, const uint8_t *d_active, const csc::tnode *d_tn, uint64_t *n_pairs)
+{
+    using namespace csc;
+    const size_t ctr_per_level = static_cast<size_t>(DT_SHARDS) * DT_CTR_STRIDE;
+    CSC_BUF(d_cnt, uint32_t, "dt_counters", ctr_per_level * (DT_MAX_LEVELS + 2));
+    uint32_t *d_pair_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 1);
+    // First guesses: 4 frontier items and 8 pairs per particle and chunk; afterwards what the last
+    // superstep needed (populations change slowly), and an overflow redoes the traversal.
+    uint32_t fr_cap = std::max<uint32_t>({ctx->dt_fr_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 4u, 4096u});
+    uint32_t pair_cap = std::max<uint32_t>({ctx->dt_pair_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u});
+    std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 2));
+    const unsigned grid = DT_SHARDS * 64u; // 2048 workgroups of 256: 8 per CU
+    uint64_t total = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        CSC_BUF(d_fa, unsigned long long, "dt_frontier_a", static_cast<size_t>(fr_cap) * DT_SHARDS);
+        CSC_BUF(d_fb, unsigned long long, "dt_frontier_b", static_cast<size_t>(fr_cap) * DT_SHARDS);
+        CSC_BUF(d_pairs, unsigned long long, "dt_pairs", static_cast<size_t>(pair_cap) * DT_SHARDS);
+        CSC_HIP(hipMemsetAsync(d_cnt, 0, hc.size() * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_bp_dual_init, dim3(cdiv(nchunks, 64)), dim3(64), 0, ctx->stream, nchunks, ctx->bvh.nn_max, ctx->bvh.nleft,
+                           d_fa, d_cnt);
+        dual_params q{};
+        q.tn = d_tn;
+        q.nn_max = ctx->bvh.nn_max;
+        q.n = n;
+        q.nb = ctx->bvh.nb;
+        q.ne = ctx->bvh.ne;
+        q.nlb = ctx->bvh.nlb;
+        q.nub = ctx->bvh.nub;
+        q.slb = reinterpret_cast<const float4 *>(d_srt_lbs);
+        q.sub = reinterpret_cast<const float4 *>(d_srt_ubs);
+        q.vidx = d_vidx;
+        q.active = d_active;
+        q.fr_cap = fr_cap;
+        q.pairs = d_pairs;
+        q.pair_cnt = d_pair_cnt;
+        q.pair_cap = pair_cap;
+        q.shard_level = 12;
+        q.shard_rank = ctx->shard_rank;
+        q.shard_n = ctx->shard_n;
+        int level = 0;
+        bool done = false;
+        ctx->kt_begin("k_bp_dual");
+        while (!done && level < DT_MAX_LEVELS) {
+            // A batch of levels, then a look at the size of the frontier they left.
+            const int batch_end = std::min(DT_MAX_LEVELS, level + (level == 0 ? 24 : 8));
+            for (; level < batch_end; ++level) {
+                q.level = static_cast<uint32_t>(level);
+                q.in = (level % 2 == 0) ? d_fa : d_fb;
+                q.out = (level % 2 == 0) ? d_fb : d_fa;
+                q.in_cnt = d_cnt + ctr_per_level * level;
+                q.out_cnt = d_cnt + ctr_per_level * (level + 1);
+                hipLaunchKernelGGL(k_bp_dual, dim3(grid), dim3(DT_BLOCK), 0, ctx->stream, q);
+            }
+            CSC_LAUNCH_CHECK();
+            CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * level, d_cnt + ctr_per_level * level, ctr_per_level * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+            CSC_HIP(hipStreamSynchronize(ctx->stream));
+            done = true;
+            for (int s = 0; s < DT_SHARDS; ++s) {
+                done = done && hc[ctr_per_level * level + static_cast<size_t>(s) * DT_CTR_STRIDE] == 0u;
+            }
+        }
+        ctx->kt_end("k_bp_dual");
+        if (!done) {
+            ctx->err = "broad phase: the dual traversal did not terminate";
+            return CSC_ERR_OVERFLOW;
+        }
+        CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, hc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t max_fr = 0, max_pr = 0;
+        for (int l = 0; l <= level; ++l) {
+            for (int s = 0; s < DT_SHARDS; ++s) {
+                max_fr = std::max(max_fr, hc[ctr_per_level * l + static_cast<size_t>(s) * DT_CTR_STRIDE]);
+            }
+        }
+        total = 0;
+        for (int s = 0; s < DT_SHARDS; ++s) {
+            const uint32_t v = hc[ctr_per_level * (DT_MAX_LEVELS + 1) + static_cast<size_t>(s) * DT_CTR_STRIDE];
+            max_pr = std::max(max_pr, v);
+            total += v;
+            ctx->bp_flat_cnt[s] = v;
+        }
+        ctx->dt_fr_cap = std::max(ctx->dt_fr_cap, max_fr + max_fr / 4u + 1024u);
+        ctx->dt_pair_cap = std::max(ctx->dt_pair_cap, max_pr + max_pr / 4u + 1024u);
+        if (max_fr <= fr_cap && max_pr <= pair_cap) {
+            ctx->bp_flat = true;
+            ctx->bp_flat_pairs = d_pairs;
+            ctx->bp_flat_cap = pair_cap;
+            ctx->bp_total = total;
+            ctx->bp_vidx = d_vidx;
+            ctx->bp_n = n;
+            ctx->bp_chunks = nchunks;
+            *n_pairs = total;
+            return CSC_OK;
+        }
+        // A frontier or the pair list overflowed (the counters kept counting): grow and redo. A
+        // truncated frontier hides part of what follows, hence the generous factor.
+        const bool truncated = max_fr > fr_cap;
+        if (truncated) {
+            fr_cap = max_fr * 4u;
+        }
+        if (truncated || max_pr > pair_cap) {
+            pair_cap = std::max(pair_cap, max_pr * (truncated ? 4u : 1u) + max_pr / 4u + 1024u);
+        }
+    }
+    ctx->err = "broad phase pair list overflow";
+    return CSC_ERR_OVERFLOW;
+}
+
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs)
 {
@@ -1042,6 +1164,14 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
                                          ctx->stream, ctx->bvh, d_vidx, d_active, d_tn));
     CSC_LAUNCH_CHECK();
     ctx->bvh_packed = true;
+    if (ctx->bp_mode < 0) {
+        const char *e = std::getenv("CASCADE_BP_MODE");
+        ctx->bp_mode = (e && std::string(e) == "walk") ? 0 : 1;
+    }
+    ctx->bp_flat = false;
+    if (ctx->bp_mode == 1 && ctx->bvh.nn_max < csc::DT_MAX_NODES && nchunks <= csc::DT_MAX_CHUNKS) {
+        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, n_pairs);
+    }
     csc::bp_params q{};
     q.n = n;
     q.nn_max = ctx->bvh.nn_max;
@@ -1174,6 +1304,33 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
     if (chunk >= ctx->bp_chunks) {
         return ctx->invalid("invalid chunk index");
     }
+    if (ctx->bp_flat) {
+        std::vector<uint32_t> vx(ctx->bp_n);
+        CSC_HIP(hipMemcpy(vx.data(), ctx->bp_vidx + static_cast<size_t>(chunk) * ctx->bp_n, vx.size() * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
+        uint64_t k = 0;
+        std::vector<unsigned long long> h;
+        for (int s = 0; s < csc::DT_SHARDS; ++s) {
+            h.resize(ctx->bp_flat_cnt[s]);
+            if (h.empty()) {
+                continue;
+            }
+            CSC_HIP(hipMemcpy(h.data(), ctx->bp_flat_pairs + static_cast<size_t>(s) * ctx->bp_flat_cap,
+                              h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (const unsigned long long rec : h) {
+                if (static_cast<uint32_t>(rec >> 56) != chunk) {
+                    continue;
+                }
+                if (k < cap) {
+                    pairs[k * 2u] = vx[static_cast<uint32_t>(rec) & 0xfffffffu];
+                    pairs[k * 2u + 1u] = vx[static_cast<uint32_t>(rec >> 28) & 0xfffffffu];
+                }
+                ++k;
+            }
+        }
+        *count = k;
+        return CSC_OK;
+    }
     const csc::pair_lists &pl = ctx->bp_pl;
     const uint32_t nb = ctx->bp_blocks;
     std::vector<uint2> order(nb);
@@ -1216,6 +1373,10 @@ struct np_source {
     const uint2 *pb_pairs = nullptr;
     const uint32_t *vidx = nullptr;
     const float *srt_recs = nullptr; // null: no pre-filter, every pair is a candidate
+    // (a') the flat pair lists of the dual traversal
+    const unsigned long long *flat_pairs = nullptr;
+    uint32_t flat_cap = 0;
+    const uint32_t *flat_cnt = nullptr;
     // (b) a ready-made candidate list {pi, pj, chunk, 0} (original indices)
     const uint4 *cand = nullptr;
     uint64_t npairs = 0; // number of pairs of the source (capacity bound for the candidates)
@@ -1293,6 +1454,17 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.pb_count = src.pb_count;
         q.pairs = src.pb_pairs;
         q.vidx = src.vidx;
+        uint32_t flat_tiles = 0;
+        if (src.flat_pairs != nullptr) {
+            q.flat_pairs = src.flat_pairs;
+            q.flat_cap = src.flat_cap;
+            for (int s = 0; s < csc::NP_FLAT_SHARDS; ++s) {
+                q.flat_cnt[s] = src.flat_cnt[s];
+                q.flat_tile_off[s] = flat_tiles;
+                flat_tiles += cdiv(src.flat_cnt[s], 64);
+            }
+            q.flat_tile_off[csc::NP_FLAT_SHARDS] = flat_tiles;
+        }
         q.srt_recs = reinterpret_cast<const float4 *>(src.srt_recs);
         q.cand = src.cand ? const_cast<uint4 *>(src.cand) : d_cand;
         q.cand_cap = cand_cap;
@@ -1312,6 +1484,12 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         if (src.cand != nullptr) {
             const uint32_t nc = static_cast<uint32_t>(src.npairs);
             CSC_HIP(hipMemcpyAsync(d_cnt + 5, &nc, sizeof(nc), hipMemcpyHostToDevice, ctx->stream));
+        } else if (src.flat_pairs != nullptr) {
+            if (src.srt_recs != nullptr) {
+                KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter_flat<true>), dim3(flat_tiles), dim3(64), 0, ctx->stream, q));
+            } else {
+                KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter_flat<false>), dim3(flat_tiles), dim3(64), 0, ctx->stream, q));
+            }
         } else if (src.srt_recs != nullptr) {
             KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter<true>), dim3(src.norder * (csc::PB_SIZE / 64)), dim3(64), 0,
                                                      ctx->stream, q));
@@ -1417,6 +1595,11 @@ int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, doub
     }
     // After a terminal-event shrink the kernels skip the pairs of the dropped chunks.
     np_source src;
+    if (ctx->bp_flat) {
+        src.flat_pairs = ctx->bp_flat_pairs;
+        src.flat_cap = ctx->bp_flat_cap;
+        src.flat_cnt = ctx->bp_flat_cnt;
+    }
     src.order = ctx->bp_order;
     src.norder = ctx->bp_blocks;
     src.pb_count = ctx->bp_pl.pb_count;

@@ -1,0 +1,336 @@
+// cascade_amd/csrc/k_bp_dual.hpp
+//
+// K6, second formulation: simultaneous (dual) traversal of the BVH against itself.
+//
+// Replaces src/sim_broad_phase.cpp:92-202 like k_broad_phase (k_bvh.hpp), with the same output
+// set. The reference walks the tree once per particle; its pair set is
+//   {(a, b) : orig_a < orig_b, box(a) overlaps box(leaf(b)), some activity flag set}
+// (see k_bvh.hpp). A parent box is the exact union of its children's boxes, so if box(a)
+// overlaps box(leaf(b)) then every pair of ancestors (X of a, Y of b) has overlapping boxes:
+// descending from (root, root) into the child pairs whose boxes overlap reaches every such
+// leaf pair exactly once, and at the leaves the reference's own test decides. This visits
+// ~2.4 node pairs per output pair (7 box tests) where the per-particle walks visit ~20 nodes
+// per output pair (1M-object LEO population: 6.0e7 node pairs against 4.8e8 node visits).
+//
+// One launch per level of the pair tree. A frontier item is a node pair of one time chunk,
+//   a | a_is_leaf << 27 | b << 28 | b_is_leaf << 55 | chunk << 56,
+// a thread expands one item: the (up to four) child pairs with overlapping boxes go to the
+// next frontier, leaf-leaf pairs to the pair list. Both outputs are compacted per workgroup
+// (ballot-free block scan, one atomic per 256 items and output kind) into DT_SHARDS independent
+// regions, each with its own counter on its own cache line: same-address atomics from
+// thousands of workgroups serialise at ~13 ns each.
+//
+// A pair is recorded as pos_a | pos_b << 28 | chunk << 56 (sorted positions within the chunk,
+// orig(pos_a) < orig(pos_b)). Limits of this encoding: 2^27 nodes per chunk, 256 chunks; the
+// caller falls back on k_broad_phase beyond them.
+//
+// Multi-GPU: every process expands the first levels completely (a few thousand items), at
+// level q.shard_level it keeps the items whose hash falls on its rank and from then on only
+// their descendants; pairs found before that level are dealt by the same hash. The subtrees of
+// distinct items are disjoint, so the processes' pair sets partition the global set.
+#pragma once
+
+#include "k_bvh.hpp"
+
+namespace csc
+{
+
+constexpr int DT_BLOCK = 256;
+constexpr int DT_SHARDS = 32;
+constexpr int DT_CTR_STRIDE = 16; // u32 counters 64 bytes apart
+constexpr int DT_MAX_LEVELS = 2 * BVH_MAX_LEVELS + 2;
+constexpr std::uint32_t DT_MAX_NODES = 1u << 27;
+constexpr std::uint32_t DT_MAX_CHUNKS = 256;
+
+struct dual_params {
+    const tnode *tn;           // [C][nn_max] wide nodes (internal nodes only)
+    std::uint32_t nn_max, n;
+    const std::uint32_t *nb, *ne; // [C][nn_max] particle range of a node
+    const float4 *nlb, *nub;      // [C][nn_max] node boxes
+    const float4 *slb, *sub;      // [C][n] particle boxes (sorted)
+    const std::uint32_t *vidx;    // [C][n]
+    const std::uint8_t *active;   // [n]
+    const unsigned long long *in; // [DT_SHARDS][fr_cap]
+    unsigned long long *out;
+    const std::uint32_t *in_cnt;  // [DT_SHARDS * DT_CTR_STRIDE]
+    std::uint32_t *out_cnt;
+    std::uint32_t fr_cap;         // frontier capacity per shard
+    unsigned long long *pairs;    // [DT_SHARDS][pair_cap]
+    std::uint32_t *pair_cnt;      // [DT_SHARDS * DT_CTR_STRIDE]
+    std::uint32_t pair_cap;
+    std::uint32_t level, shard_level, shard_rank, shard_n;
+};
+
+CSC_DEV unsigned long long dt_item(std::uint32_t a, bool al, std::uint32_t b, bool bl, std::uint32_t c)
+{
+    return static_cast<unsigned long long>(a) | (static_cast<unsigned long long>(al) << 27)
+           | (static_cast<unsigned long long>(b) << 28) | (static_cast<unsigned long long>(bl) << 55)
+           | (static_cast<unsigned long long>(c) << 56);
+}
+CSC_DEV unsigned long long dt_pair(std::uint32_t pa, std::uint32_t pb, std::uint32_t c)
+{
+    return static_cast<unsigned long long>(pa) | (static_cast<unsigned long long>(pb) << 28)
+           | (static_cast<unsigned long long>(c) << 56);
+}
+CSC_DEV std::uint32_t dt_hash(unsigned long long v)
+{
+    v ^= v >> 33;
+    v *= 0xff51afd7ed558ccdull;
+    v ^= v >> 33;
+    v *= 0xc4ceb9fe1a85ec53ull;
+    v ^= v >> 33;
+    return static_cast<std::uint32_t>(v);
+}
+
+// One side of a node pair: a child of an internal node, or a leaf carried over from the level above.
+struct dt_side {
+    float4 lb, ub;
+    std::uint32_t idx;   // canonical node index
+    bool leaf;
+    std::uint32_t begin, end; // particle range (leaves)
+    std::uint32_t orig;       // original index of the first particle (leaves)
+    std::uint32_t act;        // activity flags of the first particle (leaves)
+};
+
+CSC_DEV dt_side dt_child(const float4 &lb, const float4 &ub, const int4 &c)
+{
+    dt_side s;
+    s.lb = lb;
+    s.ub = ub;
+    s.leaf = c.x < 0;
+    const std::uint32_t code = static_cast<std::uint32_t>(-1 - c.x);
+    s.idx = s.leaf ? (code >> 2) : static_cast<std::uint32_t>(c.x);
+    s.act = code & 3u;
+    s.begin = static_cast<std::uint32_t>(c.y);
+    s.end = static_cast<std::uint32_t>(c.z);
+    s.orig = static_cast<std::uint32_t>(c.w);
+    return s;
+}
+
+CSC_DEV std::uint32_t dt_wave_incl_scan(std::uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const std::uint32_t t = __shfl_up(v, d);
+        if (lane >= d) {
+            v += t;
+        }
+    }
+    return v;
+}
+
+// Seeds the frontier of level 0 with (root, root) of every chunk (shard 0).
+__global__ void k_bp_dual_init(std::uint32_t nchunks, std::uint32_t nn_max, const std::int32_t *nleft, unsigned long long *out,
+                               std::uint32_t *out_cnt)
+{
+    const std::uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchunks) {
+        const bool leaf = nleft[static_cast<std::size_t>(c) * nn_max] < 0;
+        out[c] = dt_item(0u, leaf, 0u, leaf, c);
+    }
+    if (c == 0u) {
+        out_cnt[0] = nchunks;
+    }
+}
+
+__global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
+{
+    __shared__ std::uint32_t s_wsum[2][DT_BLOCK / 64];
+    __shared__ std::uint32_t s_base[2];
+    const std::uint32_t shard = blockIdx.x % DT_SHARDS;
+    const std::uint32_t tile_stride = gridDim.x / DT_SHARDS;
+    const std::uint32_t cnt_raw = q.in_cnt[shard * DT_CTR_STRIDE];
+    const std::uint32_t cnt = cnt_raw < q.fr_cap ? cnt_raw : q.fr_cap;
+    const unsigned long long *in = q.in + static_cast<std::size_t>(shard) * q.fr_cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool deal_pairs = q.shard_n > 1u && q.level < q.shard_level;
+    const bool deal_items = q.shard_n > 1u && q.level + 1u == q.shard_level;
+
+    for (std::uint32_t tile = blockIdx.x / DT_SHARDS; static_cast<std::uint64_t>(tile) * DT_BLOCK < cnt; tile += tile_stride) {
+        const std::uint32_t k = tile * DT_BLOCK + threadIdx.x;
+        // The outputs of successive tiles go to successive shards: a frontier that starts in one
+        // shard (the roots) is spread over all of them within a few levels.
+        const std::uint32_t oshard = (shard + tile) % DT_SHARDS;
+        unsigned long long *out = q.out + static_cast<std::size_t>(oshard) * q.fr_cap;
+        unsigned long long *pout = q.pairs + static_cast<std::size_t>(oshard) * q.pair_cap;
+        std::uint32_t *out_cnt = q.out_cnt + oshard * DT_CTR_STRIDE;
+        std::uint32_t *pair_cnt = q.pair_cnt + oshard * DT_CTR_STRIDE;
+        // Up to four outputs, one per (statically numbered) child pair: kind 1 = frontier item,
+        // 2 = pair. Static slots keep the records in registers.
+        unsigned long long rec_out[4] = {0, 0, 0, 0};
+        std::uint32_t kind[4] = {0, 0, 0, 0};
+        if (k < cnt) {
+            const unsigned long long it = in[k];
+            const std::uint32_t a = static_cast<std::uint32_t>(it) & (DT_MAX_NODES - 1u);
+            const bool al = (it >> 27) & 1u;
+            const std::uint32_t b = static_cast<std::uint32_t>(it >> 28) & (DT_MAX_NODES - 1u);
+            const bool bl = (it >> 55) & 1u;
+            const std::uint32_t c = static_cast<std::uint32_t>(it >> 56);
+            const std::size_t no = static_cast<std::size_t>(c) * q.nn_max, po = static_cast<std::size_t>(c) * q.n;
+            const tnode *tn = q.tn + no;
+
+            // Exact leaf-leaf test of the reference for every member pair (multi-particle leaves:
+            // the particle with the smaller original index queries the LEAF box of the other,
+            // src/sim_broad_phase.cpp:161-185). Rare: appended one by one.
+            auto slow_pairs = [&](const dt_side &x, const dt_side &y, bool same) {
+                for (std::uint32_t p = x.begin; p != x.end; ++p) {
+                    for (std::uint32_t r = same ? p + 1u : y.begin; r != y.end; ++r) {
+                        const std::uint32_t op = q.vidx[po + p], orr = q.vidx[po + r];
+                        if ((q.active[op] | q.active[orr]) == 0) {
+                            continue;
+                        }
+                        const bool p_first = op < orr;
+                        const std::uint32_t qa = p_first ? p : r, qb = p_first ? r : p;
+                        const dt_side &leaf_b = p_first ? y : x;
+                        if (!same && !bp_overlap(q.slb[po + qa], q.sub[po + qa], leaf_b.lb, leaf_b.ub)) {
+                            continue;
+                        }
+                        const unsigned long long rec = dt_pair(qa, qb, c);
+                        if (deal_pairs && dt_hash(rec) % q.shard_n != q.shard_rank) {
+                            continue;
+                        }
+                        const std::uint32_t slot = atomicAdd(pair_cnt, 1u);
+                        if (slot < q.pair_cap) {
+                            pout[slot] = rec;
+                        }
+                    }
+                }
+            };
+            // A pair of distinct nodes whose boxes overlap.
+            auto visit = [&](const dt_side &x, const dt_side &y, const int slot) {
+                if (x.leaf && y.leaf) {
+                    if (x.end - x.begin == 1u && y.end - y.begin == 1u) {
+                        if ((x.act | y.act) != 0u) {
+                            const bool x_first = x.orig < y.orig;
+                            const unsigned long long rec = dt_pair(x_first ? x.begin : y.begin, x_first ? y.begin : x.begin, c);
+                            if (!deal_pairs || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                                rec_out[slot] = rec;
+                                kind[slot] = 2u;
+                            }
+                        }
+                    } else {
+                        slow_pairs(x, y, false);
+                    }
+                } else {
+                    const unsigned long long rec = dt_item(x.idx, x.leaf, y.idx, y.leaf, c);
+                    if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                        rec_out[slot] = rec;
+                        kind[slot] = 1u;
+                    }
+                }
+            };
+            auto self = [&](const dt_side &x, const int slot) {
+                if (!x.leaf || x.end - x.begin > 1u) {
+                    const unsigned long long rec = dt_item(x.idx, x.leaf, x.idx, x.leaf, c);
+                    if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                        rec_out[slot] = rec;
+                        kind[slot] = 1u;
+                    }
+                }
+            };
+            auto carried_leaf = [&](std::uint32_t idx) {
+                dt_side s;
+                s.lb = q.nlb[no + idx];
+                s.ub = q.nub[no + idx];
+                s.idx = idx;
+                s.leaf = true;
+                s.begin = q.nb[no + idx];
+                s.end = q.ne[no + idx];
+                s.orig = q.vidx[po + s.begin];
+                s.act = q.active[s.orig];
+                return s;
+            };
+
+            if (a == b) {
+                if (al) {
+                    const dt_side x = carried_leaf(a);
+                    slow_pairs(x, x, true);
+                } else {
+                    const tnode t = tn[a];
+                    const dt_side x0 = dt_child(t.lb0, t.ub0, t.c0), x1 = dt_child(t.lb1, t.ub1, t.c1);
+                    self(x0, 0);
+                    self(x1, 1);
+                    if (bp_overlap(x0.lb, x0.ub, x1.lb, x1.ub)) {
+                        visit(x0, x1, 2);
+                    }
+                }
+            } else if (!al && !bl) {
+                const tnode ta = tn[a], tb = tn[b];
+                const dt_side x0 = dt_child(ta.lb0, ta.ub0, ta.c0), x1 = dt_child(ta.lb1, ta.ub1, ta.c1);
+                const dt_side y0 = dt_child(tb.lb0, tb.ub0, tb.c0), y1 = dt_child(tb.lb1, tb.ub1, tb.c1);
+                if (bp_overlap(x0.lb, x0.ub, y0.lb, y0.ub)) {
+                    visit(x0, y0, 0);
+                }
+                if (bp_overlap(x0.lb, x0.ub, y1.lb, y1.ub)) {
+                    visit(x0, y1, 1);
+                }
+                if (bp_overlap(x1.lb, x1.ub, y0.lb, y0.ub)) {
+                    visit(x1, y0, 2);
+                }
+                if (bp_overlap(x1.lb, x1.ub, y1.lb, y1.ub)) {
+                    visit(x1, y1, 3);
+                }
+            } else {
+                // One leaf carried over, one internal node.
+                const std::uint32_t li = al ? a : b, ni = al ? b : a;
+                const dt_side x = carried_leaf(li);
+                const tnode t = tn[ni];
+                const dt_side y0 = dt_child(t.lb0, t.ub0, t.c0), y1 = dt_child(t.lb1, t.ub1, t.c1);
+                if (bp_overlap(x.lb, x.ub, y0.lb, y0.ub)) {
+                    visit(x, y0, 0);
+                }
+                if (bp_overlap(x.lb, x.ub, y1.lb, y1.ub)) {
+                    visit(x, y1, 1);
+                }
+            }
+        }
+
+        // Workgroup compaction of both outputs: one atomic per output kind and tile.
+        std::uint32_t nf = 0, np = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            nf += kind[j] == 1u;
+            np += kind[j] == 2u;
+        }
+        const std::uint32_t inc_f = dt_wave_incl_scan(nf, lane), inc_p = dt_wave_incl_scan(np, lane);
+        if (lane == 63) {
+            s_wsum[0][wave] = inc_f;
+            s_wsum[1][wave] = inc_p;
+        }
+        __syncthreads();
+        std::uint32_t off_f = inc_f - nf, off_p = inc_p - np, tot_f = 0, tot_p = 0;
+#pragma unroll
+        for (int w = 0; w < DT_BLOCK / 64; ++w) {
+            const std::uint32_t wf = s_wsum[0][w], wp = s_wsum[1][w];
+            if (w < wave) {
+                off_f += wf;
+                off_p += wp;
+            }
+            tot_f += wf;
+            tot_p += wp;
+        }
+        if (threadIdx.x == 0) {
+            s_base[0] = tot_f ? atomicAdd(out_cnt, tot_f) : 0u;
+            s_base[1] = tot_p ? atomicAdd(pair_cnt, tot_p) : 0u;
+        }
+        __syncthreads();
+        std::uint32_t pos_f = s_base[0] + off_f, pos_p = s_base[1] + off_p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kind[j] == 1u) {
+                if (pos_f < q.fr_cap) {
+                    out[pos_f] = rec_out[j];
+                }
+                ++pos_f;
+            } else if (kind[j] == 2u) {
+                if (pos_p < q.pair_cap) {
+                    pout[pos_p] = rec_out[j];
+                }
+                ++pos_p;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace csc

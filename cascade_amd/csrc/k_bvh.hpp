@@ -394,8 +394,8 @@ __global__ __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t ch
 // longer than the tree depth.
 //
 // A child descriptor is {tag, begin, end, orig}: tag = the child's own canonical index when it
-// is internal; for a leaf tag = -1 - act where act is the activity byte of its (first)
-// particle; [begin, end) the particle range; orig the original index of the first particle.
+// is internal; for a leaf tag = -1 - (index << 2 | act) where act is the activity byte of its
+// (first) particle; [begin, end) the particle range; orig the original index of the first particle.
 // ---------------------------------------------------------------------------
 struct tnode {
     float4 lb0, ub0, lb1, ub1;
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_
     t.ub1 = b.nub[no + l + 1];
     const std::uint32_t b0 = b.nb[no + l], b1 = b.nb[no + l + 1];
     const std::uint32_t o0 = vx[b0], o1 = vx[b1];
-    const int tag0 = b.nleft[no + l] < 0 ? -1 - static_cast<int>(active[o0]) : l;
-    const int tag1 = b.nleft[no + l + 1] < 0 ? -1 - static_cast<int>(active[o1]) : l + 1;
+    const int tag0 = b.nleft[no + l] < 0 ? -1 - ((l << 2) | static_cast<int>(active[o0] & 3u)) : l;
+    const int tag1 = b.nleft[no + l + 1] < 0 ? -1 - (((l + 1) << 2) | static_cast<int>(active[o1] & 3u)) : l + 1;
     t.c0 = make_int4(tag0, static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(o0));
     t.c1 = make_int4(tag1, static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]), static_cast<int>(o1));
     tn[no + p] = t;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
     auto leaf = [&](unsigned long long hit, int tag, int begin, int end, int orig) {
         if (end - begin == 1) {
             const std::uint32_t oi = static_cast<std::uint32_t>(orig);
-            emit(hit & __ballot(orig_p < oi) & (tag != -1 ? ~0ull : act_mask), static_cast<std::uint32_t>(begin));
+            emit(hit & __ballot(orig_p < oi) & (((-1 - tag) & 3) != 0 ? ~0ull : act_mask), static_cast<std::uint32_t>(begin));
         } else {
             // Multi-particle leaf (equal Morton codes): the test is against the LEAF box for
             // every member (src/sim_broad_phase.cpp:161-168).

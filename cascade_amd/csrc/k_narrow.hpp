@@ -42,6 +42,8 @@ struct conj_rec {
 };
 static_assert(sizeof(conj_rec) == 128, "conjunction layout");
 
+constexpr int NP_FLAT_SHARDS = 32; // = DT_SHARDS of k_bp_dual.hpp
+
 struct np_params {
     std::uint32_t n;       // particles
     std::uint32_t nchunks; // chunks (after a possible STE shrink)
@@ -60,6 +62,11 @@ struct np_params {
     std::uint32_t norder;
     const std::uint32_t *pb_count; // pairs in each block
     const uint2 *pairs;           // [block][PB_SIZE] {pos_i, pos_j}
+    // ... or the flat pair lists of the dual traversal (k_bp_dual.hpp): [NP_FLAT_SHARDS][flat_cap]
+    const unsigned long long *flat_pairs;
+    std::uint32_t flat_cap;
+    std::uint32_t flat_cnt[NP_FLAT_SHARDS];          // pairs of each list
+    std::uint32_t flat_tile_off[NP_FLAT_SHARDS + 1]; // first 64-pair tile (= workgroup) of each list
     const std::uint32_t *vidx;    // [C][n] sorted position -> original index
     const float4 *srt_recs;       // [C][n][4] sampled-trajectory records in sorted order
     double thr_extra;             // conjunction threshold (0 when conjunctions are not tracked)
@@ -422,6 +429,38 @@ CSC_DEV double np_rsum2(const np_params &q, std::uint32_t pi, std::uint32_t pj)
 // on the 1M-object LEO population: 0.1 % of the AABB pairs survive.
 // One lane per pair, pair blocks in group-major order; FILTER = false passes every pair on
 // (used to check that the filter does not change any result).
+// The geometric exclusion test for the particles at sorted positions pa, pb of the chunk whose
+// arrays start at offset co. Returns false when the pair can be dropped.
+CSC_DEV bool np_prefilter_keep(const np_params &q, std::size_t co, std::uint32_t pa, std::uint32_t pb)
+{
+    const float4 *ra = q.srt_recs + (co + pa) * 4u, *rb = q.srt_recs + (co + pb) * 4u;
+    const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
+    const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
+    // Sample differences d_s = a_s - b_s, s = 0..4 (x, y, z).
+    const float dx[5] = {a0.x - b0.x, a0.w - b0.w, a1.z - b1.z, a2.y - b2.y, a3.x - b3.x};
+    const float dy[5] = {a0.y - b0.y, a1.x - b1.x, a1.w - b1.w, a2.z - b2.z, a3.y - b3.y};
+    const float dz[5] = {a0.z - b0.z, a1.y - b1.y, a2.x - b2.x, a2.w - b2.w, a3.z - b3.z};
+    const float thr = (static_cast<float>(q.thr_extra) + a3.w + b3.w) * 1.000002f;
+    const float thr2 = thr * thr * 1.000002f;
+    bool keep = !(thr2 < __builtin_huge_valf()); // invalid record (dev = +inf) or overflow: never excluded
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        // min over u in [0, 1] of |d_s + u (d_{s+1} - d_s)|^2
+        const float ex = dx[sidx + 1] - dx[sidx], ey = dy[sidx + 1] - dy[sidx], ez = dz[sidx + 1] - dz[sidx];
+        const float ee = ex * ex + ey * ey + ez * ez;
+        const float de = dx[sidx] * ex + dy[sidx] * ey + dz[sidx] * ez;
+        float u = ee > 0.f ? -de / ee : 0.f;
+        u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
+        const float mx = dx[sidx] + u * ex, my = dy[sidx] + u * ey, mz = dz[sidx] + u * ez;
+        const float m2 = mx * mx + my * my + mz * mz;
+        // Any u in [0, 1] gives an upper bound of the true minimum only if it IS the minimiser;
+        // rounding of u moves the point along the segment by ~1e-7 |e|, which the margin in dev
+        // and the factor on thr absorb. NaNs compare false: the pair is kept.
+        keep = keep || !(m2 > thr2);
+    }
+    return keep;
+}
+
 template <bool FILTER>
 __global__ __launch_bounds__(64) void k_np_prefilter(const np_params q)
 {
@@ -436,36 +475,46 @@ __global__ __launch_bounds__(64) void k_np_prefilter(const np_params q)
     const std::size_t co = static_cast<std::size_t>(c) * q.n;
     bool keep = true;
     if constexpr (FILTER) {
-        const float4 *ra = q.srt_recs + (co + rec.x) * 4u, *rb = q.srt_recs + (co + rec.y) * 4u;
-        const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
-        const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
-        // Sample differences d_s = a_s - b_s, s = 0..4 (x, y, z).
-        const float dx[5] = {a0.x - b0.x, a0.w - b0.w, a1.z - b1.z, a2.y - b2.y, a3.x - b3.x};
-        const float dy[5] = {a0.y - b0.y, a1.x - b1.x, a1.w - b1.w, a2.z - b2.z, a3.y - b3.y};
-        const float dz[5] = {a0.z - b0.z, a1.y - b1.y, a2.x - b2.x, a2.w - b2.w, a3.z - b3.z};
-        const float thr = (static_cast<float>(q.thr_extra) + a3.w + b3.w) * 1.000002f;
-        const float thr2 = thr * thr * 1.000002f;
-        keep = !(thr2 < __builtin_huge_valf()); // invalid record (dev = +inf) or overflow: never excluded
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            // min over u in [0, 1] of |d_s + u (d_{s+1} - d_s)|^2
-            const float ex = dx[sidx + 1] - dx[sidx], ey = dy[sidx + 1] - dy[sidx], ez = dz[sidx + 1] - dz[sidx];
-            const float ee = ex * ex + ey * ey + ez * ez;
-            const float de = dx[sidx] * ex + dy[sidx] * ey + dz[sidx] * ez;
-            float u = ee > 0.f ? -de / ee : 0.f;
-            u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
-            const float mx = dx[sidx] + u * ex, my = dy[sidx] + u * ey, mz = dz[sidx] + u * ez;
-            const float m2 = mx * mx + my * my + mz * mz;
-            // Any u in [0, 1] gives an upper bound of the true minimum only if it IS the minimiser;
-            // rounding of u moves the point along the segment by ~1e-7 |e|, which the margin in dev
-            // and the factor on thr absorb. NaNs compare false: the pair is kept.
-            keep = keep || !(m2 > thr2);
-        }
+        keep = np_prefilter_keep(q, co, rec.x, rec.y);
     }
     if (keep) {
         const std::uint32_t slot = atomicAdd(&q.counters[5], 1u);
         if (slot < q.cand_cap) {
             q.cand[slot] = make_uint4(q.vidx[co + rec.x], q.vidx[co + rec.y], c, 0u);
+        }
+    }
+}
+
+// The same over the flat pair lists of the dual traversal (k_bp_dual.hpp): NP_FLAT_SHARDS lists
+// of packed pairs pos_a | pos_b << 28 | chunk << 56; workgroup w handles 64 pairs of the shard
+// whose tile range [flat_tile_off[s], flat_tile_off[s + 1]) contains w.
+template <bool FILTER>
+__global__ __launch_bounds__(64) void k_np_prefilter_flat(const np_params q)
+{
+    const std::uint32_t wg = blockIdx.x;
+    int s = 0;
+    while (s + 1 < NP_FLAT_SHARDS && wg >= q.flat_tile_off[s + 1]) {
+        ++s;
+    }
+    const std::uint32_t t = (wg - q.flat_tile_off[s]) * 64u + threadIdx.x;
+    if (t >= q.flat_cnt[s]) {
+        return;
+    }
+    const unsigned long long rec = q.flat_pairs[static_cast<std::size_t>(s) * q.flat_cap + t];
+    const std::uint32_t pa = static_cast<std::uint32_t>(rec) & 0xfffffffu, pb = static_cast<std::uint32_t>(rec >> 28) & 0xfffffffu;
+    const std::uint32_t c = static_cast<std::uint32_t>(rec >> 56);
+    if (c >= q.nchunks) {
+        return;
+    }
+    const std::size_t co = static_cast<std::size_t>(c) * q.n;
+    bool keep = true;
+    if constexpr (FILTER) {
+        keep = np_prefilter_keep(q, co, pa, pb);
+    }
+    if (keep) {
+        const std::uint32_t slot = atomicAdd(&q.counters[5], 1u);
+        if (slot < q.cand_cap) {
+            q.cand[slot] = make_uint4(q.vidx[co + pa], q.vidx[co + pb], c, 0u);
         }
     }
 }
