@@ -43,6 +43,9 @@ BYTES = {
     "k_propagate": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28),
     "k_np_fex": lambda u: u["pair_intervals"] * 1008,
     "k_broad_phase": lambda u: u["bp_nodes_visited"] * 44 + u["pairs"] * 8,
+    # Dual traversal: per expanded node pair two node records of 44 B (box + links, the figure SURVEY
+    # 8d uses per node visit) and one frontier item in, one out (8 B each); 8 B per output pair.
+    "k_bp_dual": lambda u: u["bp_node_pairs"] * (2 * 44 + 16) + u["pairs"] * 8,
     "k_rs_scatter": lambda u: u["sort_keys"] * 24,
     "k_rs_hist": lambda u: u["sort_keys"] * 8,
 }
@@ -167,7 +170,7 @@ def main():
     tot_kernel_ms = sum(v[1] for v in kern.values())
     dom = max(kern, key=lambda k: kern[k][1])
     # Units of the last step (populations change slowly; the counts of all steps agree to <0.1 %).
-    units = dict(n=N, nchunks=args.n_par_ct, substeps=s.last_total_substeps, pairs=pairs / args.steps, pair_intervals=pairs / args.steps * max(1.0, s.last_total_substeps / (N * args.n_par_ct)), sort_keys=N * args.n_par_ct, bp_nodes_visited=s.bp_nodes_visited())
+    units = dict(n=N, nchunks=args.n_par_ct, substeps=s.last_total_substeps, pairs=pairs / args.steps, pair_intervals=pairs / args.steps * max(1.0, s.last_total_substeps / (N * args.n_par_ct)), sort_keys=N * args.n_par_ct, bp_nodes_visited=s.bp_nodes_visited(), bp_node_pairs=s.last_bp_node_pairs)
     if sharded:
         workload = "random_leo_pop_kep scaled to %d objects, one simulation over %d GPUs (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42)" % (N, world, args.ct, args.n_par_ct)
     else:

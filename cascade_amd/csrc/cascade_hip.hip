@@ -65,6 +65,7 @@ struct csc_ctx {
     uint32_t bp_flat_cap = 0;
     uint32_t bp_flat_cnt[csc::DT_SHARDS] = {};
     uint32_t dt_fr_cap = 0, dt_pair_cap = 0;
+    uint64_t bp_node_pairs = 0;
     int bp_mode = -1; // -1: read CASCADE_BP_MODE once; 0 per-particle walks, 1 dual traversal
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
@@ -1027,6 +1028,11 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
 
 // ---- K6 --------------------------------------------------------------------------------
 
+uint64_t csc_broad_phase_node_pairs(csc_ctx *ctx)
+{
+    return ctx->bp_node_pairs;
+}
+
 int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
 {
     if (nranks == 0u || rank >= nranks) {
@@ -1041,7 +1047,8 @@ int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
 // on the device; the host looks at them every few levels to stop.
 static_assert(csc::NP_FLAT_SHARDS == csc::DT_SHARDS, "flat pair lists");
 static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
-                            const uint32_t *d_vidx, const uint8_t *d_active, const csc::tnode *d_tn, uint64_t *n_pairs)
+                            const uint32_t *d_vidx, const uint8_t *d_active, const csc::tnode *d_tn, const uint8_t *d_sact,
+                            uint64_t *n_pairs)
 {
     using namespace csc;
     const size_t ctr_per_level = static_cast<size_t>(DT_SHARDS) * DT_CTR_STRIDE;
@@ -1073,6 +1080,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         q.sub = reinterpret_cast<const float4 *>(d_srt_ubs);
         q.vidx = d_vidx;
         q.active = d_active;
+        q.sact = d_sact;
         q.fr_cap = fr_cap;
         q.pairs = d_pairs;
         q.pair_cnt = d_pair_cnt;
@@ -1085,7 +1093,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         ctx->kt_begin("k_bp_dual");
         while (!done && level < DT_MAX_LEVELS) {
             // A batch of levels, then a look at the size of the frontier they left.
-            const int batch_end = std::min(DT_MAX_LEVELS, level + (level == 0 ? 24 : 8));
+            const int batch_end = std::min(DT_MAX_LEVELS, level + (level == 0 ? 32 : 8));
             for (; level < batch_end; ++level) {
                 q.level = static_cast<uint32_t>(level);
                 q.in = (level % 2 == 0) ? d_fa : d_fb;
@@ -1108,14 +1116,20 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
             ctx->err = "broad phase: the dual traversal did not terminate";
             return CSC_ERR_OVERFLOW;
         }
-        CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, hc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, ctr_per_level * (level + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, ctr_per_level * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
         uint32_t max_fr = 0, max_pr = 0;
+        uint64_t items = 0;
         for (int l = 0; l <= level; ++l) {
             for (int s = 0; s < DT_SHARDS; ++s) {
-                max_fr = std::max(max_fr, hc[ctr_per_level * l + static_cast<size_t>(s) * DT_CTR_STRIDE]);
+                const uint32_t v = hc[ctr_per_level * l + static_cast<size_t>(s) * DT_CTR_STRIDE];
+                max_fr = std::max(max_fr, v);
+                items += v;
             }
         }
+        ctx->bp_node_pairs = items;
         total = 0;
         for (int s = 0; s < DT_SHARDS; ++s) {
             const uint32_t v = hc[ctr_per_level * (DT_MAX_LEVELS + 1) + static_cast<size_t>(s) * DT_CTR_STRIDE];
@@ -1160,8 +1174,9 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     CSC_BUF(d_tn, csc::tnode, "bvh_tnodes", cnn);
     // Wide traversal nodes (need the Morton permutation and the activity flags for the leaf
     // descriptors, so they are rebuilt on every call).
+    CSC_BUF(d_sact, uint8_t, "bvh_sorted_active", static_cast<size_t>(ctx->bvh_chunks) * n);
     KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
-                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn));
+                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn, d_sact));
     CSC_LAUNCH_CHECK();
     ctx->bvh_packed = true;
     if (ctx->bp_mode < 0) {
@@ -1169,8 +1184,9 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
         ctx->bp_mode = (e && std::string(e) == "walk") ? 0 : 1;
     }
     ctx->bp_flat = false;
+    ctx->bp_node_pairs = 0;
     if (ctx->bp_mode == 1 && ctx->bvh.nn_max < csc::DT_MAX_NODES && nchunks <= csc::DT_MAX_CHUNKS) {
-        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, n_pairs);
+        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, n_pairs);
     }
     csc::bp_params q{};
     q.n = n;

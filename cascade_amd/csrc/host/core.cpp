@@ -339,6 +339,7 @@ PYBIND11_MODULE(core, m)
         .def("download_state", &sim::download_state)
         .def_property_readonly("last_bp_pairs", [](const sim &s) { return s.get_step_stats().bp_pairs; })
         .def_property_readonly("last_np_candidates", [](const sim &s) { return s.get_step_stats().np_candidates; })
+        .def_property_readonly("last_bp_node_pairs", [](const sim &s) { return s.get_step_stats().bp_node_pairs; })
         .def_property_readonly("last_total_substeps", [](const sim &s) { return s.get_step_stats().total_substeps; })
         .def_property_readonly("last_nchunks", [](const sim &s) { return s.get_step_stats().nchunks; })
         .def_property_readonly("last_collisions",

@@ -1106,6 +1106,7 @@ outcome sim::step()
     d.chk(csc_narrow_phase_get(ctx, coll.data(), coll.size(), conj.data(), conj.size()));
 
     d.stats.bp_pairs = npairs;
+    d.stats.bp_node_pairs = csc_broad_phase_node_pairs(ctx);
     d.stats.np_candidates = csc_narrow_phase_candidates(ctx);
     d.stats.total_substeps = tot;
     d.stats.nchunks = nchunks;

@@ -13,7 +13,10 @@
 // per output pair (1M-object LEO population: 6.0e7 node pairs against 4.8e8 node visits).
 //
 // One launch per level of the pair tree. A frontier item is a node pair of one time chunk,
-//   a | a_is_leaf << 27 | b << 28 | b_is_leaf << 55 | chunk << 56,
+//   a | a_kind << 26 | b << 28 | b_kind << 54 | chunk << 56,
+// kind 0: internal node (value = canonical index), 1: single-particle leaf (value = its sorted
+// position: box, original index and activity come from the sorted particle arrays with no
+// dependent loads), 2: multi-particle leaf (value = canonical index; rare: equal Morton codes),
 // a thread expands one item: the (up to four) child pairs with overlapping boxes go to the
 // next frontier, leaf-leaf pairs to the pair list. Both outputs are compacted per workgroup
 // (ballot-free block scan, one atomic per 256 items and output kind) into DT_SHARDS independent
@@ -21,7 +24,7 @@
 // thousands of workgroups serialise at ~13 ns each.
 //
 // A pair is recorded as pos_a | pos_b << 28 | chunk << 56 (sorted positions within the chunk,
-// orig(pos_a) < orig(pos_b)). Limits of this encoding: 2^27 nodes per chunk, 256 chunks; the
+// orig(pos_a) < orig(pos_b)). Limits of this encoding: 2^26 nodes per chunk, 256 chunks; the
 // caller falls back on k_broad_phase beyond them.
 //
 // Multi-GPU: every process expands the first levels completely (a few thousand items), at
@@ -39,7 +42,7 @@ constexpr int DT_BLOCK = 256;
 constexpr int DT_SHARDS = 32;
 constexpr int DT_CTR_STRIDE = 16; // u32 counters 64 bytes apart
 constexpr int DT_MAX_LEVELS = 2 * BVH_MAX_LEVELS + 2;
-constexpr std::uint32_t DT_MAX_NODES = 1u << 27;
+constexpr std::uint32_t DT_MAX_NODES = 1u << 26;
 constexpr std::uint32_t DT_MAX_CHUNKS = 256;
 
 struct dual_params {
@@ -50,6 +53,7 @@ struct dual_params {
     const float4 *slb, *sub;      // [C][n] particle boxes (sorted)
     const std::uint32_t *vidx;    // [C][n]
     const std::uint8_t *active;   // [n]
+    const std::uint8_t *sact;     // [C][n] activity flags by sorted position (single-particle leaves)
     const unsigned long long *in; // [DT_SHARDS][fr_cap]
     unsigned long long *out;
     const std::uint32_t *in_cnt;  // [DT_SHARDS * DT_CTR_STRIDE]
@@ -61,10 +65,12 @@ struct dual_params {
     std::uint32_t level, shard_level, shard_rank, shard_n;
 };
 
-CSC_DEV unsigned long long dt_item(std::uint32_t a, bool al, std::uint32_t b, bool bl, std::uint32_t c)
+enum : std::uint32_t { DT_INTERNAL = 0, DT_LEAF1 = 1, DT_LEAFN = 2 };
+
+CSC_DEV unsigned long long dt_item(std::uint32_t a, std::uint32_t ak, std::uint32_t b, std::uint32_t bk, std::uint32_t c)
 {
-    return static_cast<unsigned long long>(a) | (static_cast<unsigned long long>(al) << 27)
-           | (static_cast<unsigned long long>(b) << 28) | (static_cast<unsigned long long>(bl) << 55)
+    return static_cast<unsigned long long>(a) | (static_cast<unsigned long long>(ak) << 26)
+           | (static_cast<unsigned long long>(b) << 28) | (static_cast<unsigned long long>(bk) << 54)
            | (static_cast<unsigned long long>(c) << 56);
 }
 CSC_DEV unsigned long long dt_pair(std::uint32_t pa, std::uint32_t pb, std::uint32_t c)
@@ -87,6 +93,15 @@ struct dt_side {
     float4 lb, ub;
     std::uint32_t idx;   // canonical node index
     bool leaf;
+    [[nodiscard]] CSC_DEV std::uint32_t kind() const
+    {
+        return !leaf ? DT_INTERNAL : (end - begin == 1u ? DT_LEAF1 : DT_LEAFN);
+    }
+    // What a frontier item stores for this side.
+    [[nodiscard]] CSC_DEV std::uint32_t value() const
+    {
+        return (leaf && end - begin == 1u) ? begin : idx;
+    }
     std::uint32_t begin, end; // particle range (leaves)
     std::uint32_t orig;       // original index of the first particle (leaves)
     std::uint32_t act;        // activity flags of the first particle (leaves)
@@ -125,8 +140,9 @@ __global__ void k_bp_dual_init(std::uint32_t nchunks, std::uint32_t nn_max, cons
 {
     const std::uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < nchunks) {
-        const bool leaf = nleft[static_cast<std::size_t>(c) * nn_max] < 0;
-        out[c] = dt_item(0u, leaf, 0u, leaf, c);
+        // A root that is a leaf: one particle (nothing to do, but harmless) or equal codes.
+        const std::uint32_t kd = nleft[static_cast<std::size_t>(c) * nn_max] < 0 ? DT_LEAFN : DT_INTERNAL;
+        out[c] = dt_item(0u, kd, 0u, kd, c);
     }
     if (c == 0u) {
         out_cnt[0] = nchunks;
@@ -162,9 +178,10 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
         if (k < cnt) {
             const unsigned long long it = in[k];
             const std::uint32_t a = static_cast<std::uint32_t>(it) & (DT_MAX_NODES - 1u);
-            const bool al = (it >> 27) & 1u;
+            const std::uint32_t ak = static_cast<std::uint32_t>(it >> 26) & 3u;
             const std::uint32_t b = static_cast<std::uint32_t>(it >> 28) & (DT_MAX_NODES - 1u);
-            const bool bl = (it >> 55) & 1u;
+            const std::uint32_t bk = static_cast<std::uint32_t>(it >> 54) & 3u;
+            const bool al = ak != DT_INTERNAL, bl = bk != DT_INTERNAL;
             const std::uint32_t c = static_cast<std::uint32_t>(it >> 56);
             const std::size_t no = static_cast<std::size_t>(c) * q.nn_max, po = static_cast<std::size_t>(c) * q.n;
             const tnode *tn = q.tn + no;
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
                         slow_pairs(x, y, false);
                     }
                 } else {
-                    const unsigned long long rec = dt_item(x.idx, x.leaf, y.idx, y.leaf, c);
+                    const unsigned long long rec = dt_item(x.value(), x.kind(), y.value(), y.kind(), c);
                     if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
                         rec_out[slot] = rec;
                         kind[slot] = 1u;
@@ -221,29 +238,41 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
             };
             auto self = [&](const dt_side &x, const int slot) {
                 if (!x.leaf || x.end - x.begin > 1u) {
-                    const unsigned long long rec = dt_item(x.idx, x.leaf, x.idx, x.leaf, c);
+                    const unsigned long long rec = dt_item(x.idx, x.kind(), x.idx, x.kind(), c);
                     if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
                         rec_out[slot] = rec;
                         kind[slot] = 1u;
                     }
                 }
             };
-            auto carried_leaf = [&](std::uint32_t idx) {
+            // A leaf carried over from the level above.
+            auto carried_leaf = [&](std::uint32_t v, std::uint32_t kd) {
                 dt_side s;
-                s.lb = q.nlb[no + idx];
-                s.ub = q.nub[no + idx];
-                s.idx = idx;
                 s.leaf = true;
-                s.begin = q.nb[no + idx];
-                s.end = q.ne[no + idx];
-                s.orig = q.vidx[po + s.begin];
-                s.act = q.active[s.orig];
+                if (kd == DT_LEAF1) {
+                    // v = sorted position: the leaf box is the particle's box; independent loads.
+                    s.lb = q.slb[po + v];
+                    s.ub = q.sub[po + v];
+                    s.idx = 0u;
+                    s.begin = v;
+                    s.end = v + 1u;
+                    s.orig = q.vidx[po + v];
+                    s.act = q.sact[po + v];
+                } else {
+                    s.lb = q.nlb[no + v];
+                    s.ub = q.nub[no + v];
+                    s.idx = v;
+                    s.begin = q.nb[no + v];
+                    s.end = q.ne[no + v];
+                    s.orig = q.vidx[po + s.begin];
+                    s.act = q.active[s.orig];
+                }
                 return s;
             };
 
-            if (a == b) {
+            if (a == b && ak == bk) {
                 if (al) {
-                    const dt_side x = carried_leaf(a);
+                    const dt_side x = carried_leaf(a, ak);
                     slow_pairs(x, x, true);
                 } else {
                     const tnode t = tn[a];
@@ -273,7 +302,7 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
             } else {
                 // One leaf carried over, one internal node.
                 const std::uint32_t li = al ? a : b, ni = al ? b : a;
-                const dt_side x = carried_leaf(li);
+                const dt_side x = carried_leaf(li, al ? ak : bk);
                 const tnode t = tn[ni];
                 const dt_side y0 = dt_child(t.lb0, t.ub0, t.c0), y1 = dt_child(t.lb1, t.ub1, t.c1);
                 if (bp_overlap(x.lb, x.ub, y0.lb, y0.ub)) {

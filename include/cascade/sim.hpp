@@ -207,6 +207,7 @@ public:
     // Measurements of the last step() (no counterpart in the reference besides its trace log).
     struct step_stats {
         std::uint64_t bp_pairs = 0;       // AABB pairs found by the broad phase
+        std::uint64_t bp_node_pairs = 0;  // node pairs expanded by the broad phase's dual traversal
         std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles
         std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)

@@ -273,6 +273,10 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
  * Synchronises (the totals are read back); *n_pairs = total over chunks. */
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs);
+/* Node pairs expanded by the last csc_broad_phase (the work units of the dual traversal,
+ * k_bp_dual.hpp: each reads two wide node records and tests up to four box pairs); 0 when the
+ * per-particle walk was used. For the roofline accounting. */
+uint64_t csc_broad_phase_node_pairs(csc_ctx *ctx);
 /* Multi-GPU query sharding (no counterpart in the reference, which is single-process): every
  * process holds the whole tree, and csc_broad_phase walks it only for the query groups dealt
  * to `rank` (runs of 16 groups of 64 Morton-consecutive particles, round-robin over `nranks`).

@@ -55,6 +55,15 @@ for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 0))
     w, nw = write.get(k, (0.0, 0))
     out["kernels"][k] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "traffic_bytes": int((2 * f + w) * 1024), "launches_sampled": nf}
+# The dual traversal is one dispatch per level: bench.py times a whole traversal as one unit, so
+# its traffic is the sum over the levels = mean per dispatch x dispatches per traversal (one
+# k_bp_dual_init per traversal).
+if "k_bp_dual" in out["kernels"] and "k_bp_dual_init" in out["kernels"]:
+    per = out["kernels"]["k_bp_dual"]["launches_sampled"] / max(1, out["kernels"]["k_bp_dual_init"]["launches_sampled"])
+    d = out["kernels"]["k_bp_dual"]
+    d["dispatches_per_traversal"] = round(per, 2)
+    d["traffic_bytes_per_dispatch"] = d["traffic_bytes"]
+    d["traffic_bytes"] = int(d["traffic_bytes"] * per)
 json.dump(out, open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
 for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes"])[:12]:
     print("%-22s fetch %10.1f KiB write %10.1f KiB traffic %8.1f MB" % (k, v["fetch_size_kib"], v["write_size_kib"], v["traffic_bytes"] / 1e6))
