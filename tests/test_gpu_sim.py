@@ -343,3 +343,40 @@ def test_single_pass_rows_change_nothing(kind, monkeypatch):
     prof = ctx.profile_get()
     assert prof["k_propagate_rows"][0] >= 2, prof.keys()
     assert n_events > 0
+
+
+@pytest.mark.gpu
+def test_broad_phase_formulations_agree(monkeypatch):
+    """The dual traversal (default) and the per-particle cooperative walks (fallback for trees
+    beyond the dual traversal's item encoding, CASCADE_BP_MODE=walk) give the same pairs, events
+    and states; so does a superstep with more chunks than the encoding holds (n_par_ct > 256)."""
+    from cascade_amd import sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(30000, seed=21)
+    st[:, 6] *= 2e3
+    def run(mode):
+        # The mode is read when the simulation's HIP context runs its first broad phase.
+        if mode:
+            monkeypatch.setenv("CASCADE_BP_MODE", mode)
+        else:
+            monkeypatch.delenv("CASCADE_BP_MODE", raising=False)
+        s = sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=2e-3)
+        out = []
+        for _ in range(3):
+            oc = s.step()
+            out.append((oc, s.interrupt_info, s.last_bp_pairs, s.last_bp_node_pairs, s.last_collisions.tobytes(), s.last_step_conjunctions.tobytes(), s.state.copy()))
+        return out
+
+    ra, rb = run("walk"), run(None)
+    for x, y in zip(ra, rb):
+        assert x[0] == y[0] and x[1] == y[1]
+        assert x[2] == y[2] and x[2] > 0
+        assert x[3] == 0 and y[3] > 0
+        assert x[4] == y[4] and x[5] == y[5]
+        assert np.array_equal(x[6], y[6])
+    c = sim(st[:300].copy(), 0.001, n_par_ct=300)
+    d = sim(st[:300].copy(), 0.001 * 300, n_par_ct=1)
+    assert c.step() == d.step()
+    assert c.last_bp_node_pairs == 0 and d.last_bp_node_pairs > 0
+    assert np.allclose(c.state, d.state, rtol=0, atol=1e-12)
