@@ -339,20 +339,19 @@ struct tape_ctx {
 // wave-uniform (scalar loads, scalar branches); the series live in the workspace
 // [slot][order][lane], so every load and store of a wave is one coalesced line. Replaces the
 // Taylor step function heyoka JIT-compiles from kw::dyn (src/sim_basic.cpp:553-577, EXTERNAL).
-template <int P>
-CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_ctx &tx)
-{
-    constexpr int L = P + 1;
-    double *ws = tx.ws;
 #define CSC_AT(slot, n) ws[(static_cast<std::size_t>(slot) * L + (n)) * 64u]
-    CSC_AT(0, 0) = t.x[0];
-    CSC_AT(1, 0) = t.y[0];
-    CSC_AT(2, 0) = t.z[0];
-    CSC_AT(3, 0) = t.vx[0];
-    CSC_AT(4, 0) = t.vy[0];
-    CSC_AT(5, 0) = t.vz[0];
-    CSC_AT(6, 0) = t.r[0];
-    for (int n = 0; n < P; ++n) {
+
+// Order N of every operation of the tape, then coefficient N + 1 of the state. The order is a
+// template parameter: every inner loop has compile-time bounds, is fully unrolled, and its
+// loads (independent of each other) are issued back to back -- one memory round trip per
+// operation instead of one per term (2.5x on the interpreter's time).
+template <int P, int N>
+struct tape_order {
+    static CSC_DEV void run(const prop_params &prm, const tape_ctx &tx)
+    {
+        constexpr int L = P + 1;
+        constexpr int n = N;
+        double *ws = tx.ws;
         const double dn = static_cast<double>(n);
         for (std::uint32_t k = 0; k < prm.tape_nops; ++k) {
             const tape_op o = prm.tape[k];
@@ -377,6 +376,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         res = CSC_AT(o.a, n) * sc;
                     } else {
                         double acc = 0;
+                        _Pragma("unroll")
                         for (int j = 0; j <= n; ++j) {
                             acc = fma(CSC_AT(o.a, j), CSC_AT(o.b, n - j), acc);
                         }
@@ -388,6 +388,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         res = CSC_AT(o.a, n) / sc;
                     } else {
                         double acc = CSC_AT(o.a, n);
+                        _Pragma("unroll")
                         for (int j = 1; j <= n; ++j) {
                             acc = fma(-CSC_AT(o.b, j), CSC_AT(o.dst, n - j), acc);
                         }
@@ -396,6 +397,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                     break;
                 case TP_RDIV: {
                     double acc = n == 0 ? sc : 0.;
+                    _Pragma("unroll")
                     for (int j = 1; j <= n; ++j) {
                         acc = fma(-CSC_AT(o.a, j), CSC_AT(o.dst, n - j), acc);
                     }
@@ -408,6 +410,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         res = a0 * a0;
                     } else {
                         double acc = 0;
+                        _Pragma("unroll")
                         for (int j = 0; 2 * j < n; ++j) {
                             acc = fma(CSC_AT(o.a, j), CSC_AT(o.a, n - j), acc);
                         }
@@ -424,6 +427,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         res = pow_order0(CSC_AT(o.a, 0), o.c);
                     } else {
                         double acc = 0;
+                        _Pragma("unroll")
                         for (int j = 0; j < n; ++j) {
                             const double cf = dn * o.c - static_cast<double>(j) * (o.c + 1.);
                             acc = fma(cf * CSC_AT(o.a, n - j), CSC_AT(o.dst, j), acc);
@@ -436,6 +440,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         res = sqrt(CSC_AT(o.a, 0));
                     } else {
                         double acc = CSC_AT(o.a, n);
+                        _Pragma("unroll")
                         for (int j = 1; j < n; ++j) {
                             acc = fma(-CSC_AT(o.dst, j), CSC_AT(o.dst, n - j), acc);
                         }
@@ -447,6 +452,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         res = det_exp(CSC_AT(o.a, 0));
                     } else {
                         double acc = 0;
+                        _Pragma("unroll")
                         for (int j = 1; j <= n; ++j) {
                             acc = fma(static_cast<double>(j) * CSC_AT(o.a, j), CSC_AT(o.dst, n - j), acc);
                         }
@@ -461,6 +467,7 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
                         cres = cos(a0);
                     } else {
                         double as = 0, ac = 0;
+                        _Pragma("unroll")
                         for (int j = 1; j <= n; ++j) {
                             const double ja = static_cast<double>(j) * CSC_AT(o.a, j);
                             as = fma(ja, CSC_AT(o.dst + 1, n - j), as);
@@ -486,7 +493,25 @@ CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_
         for (int c = 0; c < 7; ++c) {
             CSC_AT(c, n + 1) = CSC_AT(prm.tape_rhs[c], n) * f;
         }
+        if constexpr (N + 1 < P) {
+            tape_order<P, N + 1>::run(prm, tx);
+        }
     }
+};
+
+template <int P>
+CSC_DEV void tape_compute_tcs(tc_regs<P> &t, const prop_params &prm, const tape_ctx &tx)
+{
+    constexpr int L = P + 1;
+    double *ws = tx.ws;
+    CSC_AT(0, 0) = t.x[0];
+    CSC_AT(1, 0) = t.y[0];
+    CSC_AT(2, 0) = t.z[0];
+    CSC_AT(3, 0) = t.vx[0];
+    CSC_AT(4, 0) = t.vy[0];
+    CSC_AT(5, 0) = t.vz[0];
+    CSC_AT(6, 0) = t.r[0];
+    tape_order<P, 0>::run(prm, tx);
 #pragma unroll
     for (int n = 1; n <= P; ++n) {
         t.x[n] = CSC_AT(0, n);
