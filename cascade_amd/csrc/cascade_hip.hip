@@ -70,7 +70,10 @@ struct csc_ctx {
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
-    std::vector<csc_conjunction> conj;
+    // Conjunction records of the last narrow phase: pinned host memory (there can be millions
+    // of 128-byte records per superstep), grow-only.
+    csc_conjunction *conj = nullptr;
+    size_t conj_cap = 0, conj_count = 0;
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
     // per-kernel HIP-event timing (csc_profile_*)
     struct ktimer {
@@ -541,6 +544,9 @@ void csc_ctx_destroy(csc_ctx *ctx)
     }
     if (ctx->d_flags) {
         (void)hipFree(ctx->d_flags);
+    }
+    if (ctx->conj) {
+        (void)hipHostFree(ctx->conj);
     }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -1409,7 +1415,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         return CSC_ERR_UNSUPPORTED;
     }
     ctx->coll.clear();
-    ctx->conj.clear();
+    ctx->conj_count = 0;
     ctx->np_candidates = 0;
     *n_coll = 0;
     *n_conj = 0;
@@ -1522,7 +1528,17 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap && h[5] <= cand_cap) {
             ctx->np_candidates = h[5];
             ctx->coll.resize(h[0]);
-            ctx->conj.resize(h[1]);
+            if (h[1] > ctx->conj_cap) {
+                if (ctx->conj) {
+                    (void)hipHostFree(ctx->conj);
+                    ctx->conj = nullptr;
+                    ctx->conj_cap = 0;
+                }
+                const size_t want = static_cast<size_t>(h[1]) + h[1] / 2u + 1024u;
+                CSC_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->conj), want * sizeof(csc_conjunction), hipHostMallocDefault));
+                ctx->conj_cap = want;
+            }
+            ctx->conj_count = h[1];
             if (h[0]) {
                 CSC_HIP(hipMemcpyAsync(ctx->coll.data(), d_coll, h[0] * sizeof(csc::coll_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
@@ -1547,9 +1563,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                                                         ctx->stream, nc, reinterpret_cast<const uint4 *>(d_conj), vres,
                                                         reinterpret_cast<uint4 *>(d_sorted)));
                 CSC_LAUNCH_CHECK();
-                CSC_HIP(hipMemcpyAsync(ctx->conj.data(), d_sorted, nc * sizeof(csc::conj_rec), hipMemcpyDeviceToHost, ctx->stream));
+                CSC_HIP(hipMemcpyAsync(ctx->conj, d_sorted, nc * sizeof(csc::conj_rec), hipMemcpyDeviceToHost, ctx->stream));
             } else if (h[1]) {
-                CSC_HIP(hipMemcpyAsync(ctx->conj.data(), d_conj, h[1] * sizeof(csc::conj_rec), hipMemcpyDeviceToHost,
+                CSC_HIP(hipMemcpyAsync(ctx->conj, d_conj, h[1] * sizeof(csc::conj_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
             }
             CSC_HIP(hipStreamSynchronize(ctx->stream));
@@ -1562,18 +1578,18 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             };
             if (dev_sorted) {
                 // Already in time order: only runs of equal times need (i, j) order.
-                for (size_t b0 = 0; b0 < ctx->conj.size();) {
+                for (size_t b0 = 0; b0 < ctx->conj_count;) {
                     size_t e0 = b0 + 1;
-                    while (e0 < ctx->conj.size() && ctx->conj[e0].time == ctx->conj[b0].time) {
+                    while (e0 < ctx->conj_count && ctx->conj[e0].time == ctx->conj[b0].time) {
                         ++e0;
                     }
                     if (e0 - b0 > 1) {
-                        std::sort(ctx->conj.begin() + static_cast<std::ptrdiff_t>(b0), ctx->conj.begin() + static_cast<std::ptrdiff_t>(e0), conj_less);
+                        std::sort(ctx->conj + b0, ctx->conj + e0, conj_less);
                     }
                     b0 = e0;
                 }
-            } else {
-                std::sort(ctx->conj.begin(), ctx->conj.end(), conj_less);
+            } else if (ctx->conj_count) {
+                std::sort(ctx->conj, ctx->conj + ctx->conj_count, conj_less);
             }
             *n_coll = h[0];
             *n_conj = h[1];
@@ -1665,9 +1681,19 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
     if (coll && !ctx->coll.empty()) {
         std::memcpy(coll, ctx->coll.data(), std::min<uint64_t>(coll_cap, ctx->coll.size()) * sizeof(csc_collision));
     }
-    if (conj && !ctx->conj.empty()) {
-        std::memcpy(conj, ctx->conj.data(), std::min<uint64_t>(conj_cap, ctx->conj.size()) * sizeof(csc_conjunction));
+    if (conj && ctx->conj_count) {
+        std::memcpy(conj, ctx->conj, std::min<uint64_t>(conj_cap, ctx->conj_count) * sizeof(csc_conjunction));
     }
+    return CSC_OK;
+}
+
+int csc_narrow_phase_view(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, const csc_conjunction **conj,
+                          uint64_t *n_conj)
+{
+    *coll = ctx->coll.data();
+    *n_coll = ctx->coll.size();
+    *conj = ctx->conj;
+    *n_conj = ctx->conj_count;
     return CSC_OK;
 }
 

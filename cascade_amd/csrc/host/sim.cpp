@@ -330,6 +330,8 @@ struct sim::sim_data {
     step_stats stats;
     std::vector<std::tuple<size_type, size_type, double>> last_coll;
     std::vector<conjunction> last_conj;
+    const csc_conjunction *last_conj_view = nullptr; // in the context, until the next narrow phase
+    std::uint64_t last_conj_n = 0;
 
     csc_ctx *ctx = nullptr;
     struct dbuf {
@@ -816,7 +818,16 @@ const std::vector<std::tuple<sim::size_type, sim::size_type, double>> &sim::get_
 
 const std::vector<sim::conjunction> &sim::get_last_step_conjunctions() const
 {
-    return m_data->last_conj;
+    auto &d = *m_data;
+    if (d.last_conj_view != nullptr) {
+        // Copied out of the context on first use.
+        d.last_conj.resize(d.last_conj_n);
+        if (d.last_conj_n) {
+            std::memcpy(static_cast<void *>(d.last_conj.data()), d.last_conj_view, d.last_conj_n * sizeof(conjunction));
+        }
+        d.last_conj_view = nullptr;
+    }
+    return d.last_conj;
 }
 
 void *sim::_get_hip_context()
@@ -1101,9 +1112,12 @@ outcome sim::step()
     std::uint32_t warn = 0;
     d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
                            d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
-    std::vector<csc_collision> coll(ncoll);
-    std::vector<csc_conjunction> conj(nconj);
-    d.chk(csc_narrow_phase_get(ctx, coll.data(), coll.size(), conj.data(), conj.size()));
+    // The event lists stay in the context (pinned host memory; a conjunction-heavy superstep
+    // yields millions of 128-byte records): no copies besides the append to m_det_conj below.
+    const csc_collision *coll_p = nullptr;
+    const csc_conjunction *conj_p = nullptr;
+    std::uint64_t ncoll_v = 0, nconj_v = 0;
+    d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
 
     d.stats.bp_pairs = npairs;
     d.stats.bp_node_pairs = csc_broad_phase_node_pairs(ctx);
@@ -1111,25 +1125,34 @@ outcome sim::step()
     d.stats.total_substeps = tot;
     d.stats.nchunks = nchunks;
     d.last_coll.clear();
-    for (const auto &c : coll) {
-        d.last_coll.emplace_back(c.i, c.j, c.time);
+    for (std::uint64_t k = 0; k < ncoll_v; ++k) {
+        d.last_coll.emplace_back(coll_p[k].i, coll_p[k].j, coll_p[k].time);
     }
-    d.last_conj.resize(conj.size());
-    if (!conj.empty()) {
-        std::memcpy(static_cast<void *>(d.last_conj.data()), conj.data(), conj.size() * sizeof(conjunction));
-    }
+    // get_last_step_conjunctions() copies them on demand.
+    d.last_conj.clear();
+    d.last_conj_view = conj_p;
+    d.last_conj_n = nconj_v;
+    std::vector<csc_collision> coll(coll_p, coll_p + ncoll_v);
+    std::vector<csc_conjunction> conj_merged; // sharded mode only
     if (d.shard_n > 1u) {
         // Merge the event lists of all processes; from here on every process works on the same
         // data (the propagation results are identical everywhere by construction).
+        d.last_conj.resize(nconj_v);
+        if (nconj_v) {
+            std::memcpy(static_cast<void *>(d.last_conj.data()), conj_p, nconj_v * sizeof(conjunction));
+        }
+        d.last_conj_view = nullptr;
         d.exchange(d.last_coll, d.last_conj);
         coll.resize(d.last_coll.size());
         for (std::size_t k = 0; k < coll.size(); ++k) {
             coll[k] = csc_collision{std::get<0>(d.last_coll[k]), std::get<1>(d.last_coll[k]), std::get<2>(d.last_coll[k])};
         }
-        conj.resize(d.last_conj.size());
-        if (!conj.empty()) {
-            std::memcpy(static_cast<void *>(conj.data()), d.last_conj.data(), conj.size() * sizeof(conjunction));
+        conj_merged.resize(d.last_conj.size());
+        if (!conj_merged.empty()) {
+            std::memcpy(static_cast<void *>(conj_merged.data()), d.last_conj.data(), conj_merged.size() * sizeof(conjunction));
         }
+        conj_p = conj_merged.data();
+        nconj_v = conj_merged.size();
     }
 
     // Outcome resolution (:1189-1345). coll is sorted by (time, i, j); a collision wins a tie
@@ -1153,7 +1176,7 @@ outcome sim::step()
         }
         m_int_info.reset();
         if (with_conj) {
-            append_conj_data(conj.data(), conj.size());
+            append_conj_data(conj_p, nconj_v);
         }
     } else {
         dense_propagate(interrupt_time);
@@ -1165,10 +1188,9 @@ outcome sim::step()
         }
         if (with_conj) {
             // Keep the conjunctions that happen before the interruption (:1329-1336).
-            const auto first = conj.begin();
-            const auto last = std::lower_bound(conj.begin(), conj.end(), d.time.hi,
-                                               [](const csc_conjunction &c, double t) { return c.time < t; });
-            append_conj_data(conj.data(), static_cast<std::size_t>(last - first));
+            const auto *last = std::lower_bound(conj_p, conj_p + nconj_v, d.time.hi,
+                                                [](const csc_conjunction &c, double t) { return c.time < t; });
+            append_conj_data(conj_p, static_cast<std::size_t>(last - conj_p));
         }
     }
     return oc;

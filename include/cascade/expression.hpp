@@ -163,6 +163,15 @@ struct par_t {
 };
 inline const expression time_expr = expression(detail::mk(detail::ex_kind::time));
 
+// "x"_var (heyoka::literals).
+inline namespace literals
+{
+inline expression operator""_var(const char *s, std::size_t n)
+{
+    return expression(std::string(s, n));
+}
+} // namespace literals
+
 template <typename... Names>
 inline std::array<expression, sizeof...(Names)> make_vars(const Names &...names)
 {

@@ -320,6 +320,11 @@ int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct
 int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,
                          uint64_t conj_cap); /* host copies, sorted by (time, i, j) */
 
+/* The same lists without a copy: pointers into the context's host arrays (pinned memory for the
+ * conjunctions), valid until the next narrow phase on this context. */
+int csc_narrow_phase_view(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, const csc_conjunction **conj,
+                          uint64_t *n_conj);
+
 /* ---- K8: dense output ------------------------------------------------------------------
  * dense_propagate (src/sim_propagate.cpp:1386-1503): state of every particle at time t
  * (relative to the superstep start) into d_out [n][6]. Asynchronous; a particle without

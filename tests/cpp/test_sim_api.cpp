@@ -168,5 +168,42 @@ int main()
         REQUIRE(oss.str() == "Total number of particles: 0\nCollisional timestep     : 0.1\n");
     }
     std::printf("test_sim_api: %d checks passed\n", g_checks);
+    // Dynamics given as expressions (test/sim_api.cpp:198-212; benchmark/haumea.cpp:114-139).
+    {
+        using eqs_t = std::vector<std::pair<expression, expression>>;
+        const std::vector<double> st = {1., .001, .001, .001, 1., .001, .001};
+        REQUIRE_THROWS_MSG(sim(st, .5, kw::dyn = eqs_t{{}}), std::invalid_argument,
+                           "6 dynamical equations are expected, but 1 were provided instead");
+        auto dyn = dynamics::kepler();
+        REQUIRE(dyn.kind == dynamics::dyn_t::kepler && dyn.size() == 6u);
+        dyn[0].first = "foo"_var;
+        REQUIRE(dyn.kind == dynamics::dyn_t::tape); // touched: no longer the built-in right-hand side
+        REQUIRE_THROWS_MSG(sim(st, .5, kw::dyn = dyn), std::invalid_argument,
+                           "The LHS of the dynamics at index 0 must be a variable named \"x\", but instead it "
+                           "is the expression \"foo\"");
+        dyn[0].first = "x"_var;
+        dyn[0].second += "a"_var;
+        REQUIRE_THROWS_MSG(sim(st, .5, kw::dyn = dyn), std::invalid_argument,
+                           "The RHS of the differential equation for the variable \"x\" contains the invalid variables "
+                           "[\"a\"] (the allowed variables are [\"x\", \"y\", \"z\", \"vx\", \"vy\", \"vz\"])");
+        // A perturbation added the way the reference's drivers do, with a runtime parameter.
+        auto d2 = dynamics::kepler(3.);
+        const auto [x, y, z] = make_vars("x", "y", "z");
+        const auto pert = par(1) * diff(pow(x * x + y * y + z * z, -1.5) * sin(time_expr), z);
+        d2[5].second += pert;
+        sim s(st, .5, kw::dyn = d2, kw::pars = std::vector<double>{0.25, 0.5});
+        REQUIRE(s.get_npars() == 2u);
+        REQUIRE(s.get_pars() == (std::vector<double>{0.25, 0.5}));
+        REQUIRE(s.get_dyn().kind == dynamics::dyn_t::tape);
+        REQUIRE(s.get_dyn() == dynamics::dyn_t(d2));
+        REQUIRE(!(s.get_dyn() == dynamics::kepler(3.)));
+        // The built-in factories keep their tag until touched.
+        REQUIRE(dynamics::simple_earth(true, false, false, false).kind == (dynamics::dyn_t::j2 | dynamics::dyn_t::drag));
+        REQUIRE(dynamics::simple_earth().kind == dynamics::dyn_t::tape); // C22S22 is on by default
+        REQUIRE(dynamics::simple_earth(true, true, true, true, true, true, true, true).npars == 2u);
+        REQUIRE_THROWS_MSG(dynamics::simple_earth(true, false, false, true, false, false, false, true, true), std::invalid_argument,
+                           "simple_earth(): the thermonets density model (a neural network evaluated by heyoka) is not "
+                           "available in this build; use the exponential density fit");
+    }
     return 0;
 }
