@@ -572,6 +572,56 @@ struct ev_poly_order {
     }
 };
 
+constexpr double ct_binom(int n, int k)
+{
+    double r = 1.;
+    for (int i = 1; i <= k; ++i) {
+        r = r * static_cast<double>(n - k + i) / static_cast<double>(i);
+    }
+    return r;
+}
+
+// First step of the root isolation, inline: true when the event polynomial g has NO root in
+// [0, h) by Descartes' rule -- the rescaled polynomial does not vanish at 0 and its reversed,
+// translated-by-1 form has no sign change. Same operations in the same order as the first
+// node of isolate_and_refine (poly_rescale, poly_rtscc; src/sim_narrow_phase.cpp:300, 329-345),
+// so the decision is the one the full search would take; it keeps the out-of-line search (and
+// the register traffic around its call) for the steps that really have a candidate root. The
+// interval test above fails for every object that moves radially towards the event surface
+// during the step, i.e. for a few lanes of almost every wave of an eccentric population.
+template <int P>
+CSC_DEV bool descartes_no_root(const double *g, double h)
+{
+    double rs[P + 1];
+    double cur_f = 1;
+#pragma unroll
+    for (int i = 0; i <= P; ++i) {
+        rs[i] = cur_f * g[i];
+        cur_f *= h;
+    }
+    if (rs[0] == 0) {
+        return false;
+    }
+    int count = 0, last = 0;
+#pragma unroll
+    for (int i = 0; i <= P; ++i) {
+        // out1[k] = rs[P - k]; out2[i] = sum_{k >= i} C(k, i) out1[k], ascending k
+        double acc = rs[P - i];
+#pragma unroll
+        for (int k = i + 1; k <= P; ++k) {
+            acc += ct_binom(k, i) * rs[P - k];
+        }
+        const int sg = sgn(acc);
+        if (sg != 0) {
+            if (last != 0 && sg != last) {
+                ++count;
+            }
+            last = sg;
+        }
+    }
+    return count == 0;
+}
+
 // Slow path of terminal-event detection: full root isolation on g over [0, h).
 // Returns the earliest accepted root or a negative value if there is none.
 template <int P>
@@ -776,7 +826,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                     double g[P + 1];
                     ev_poly_order<P, 0>::run(t, g, 1., 1., 1.);
                     g[0] -= prm.exit_c0;
-                    if (!fex_excluded<P>(g, h)) {
+                    if (!fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
                         const double rt = event_first_root<P>(g, h, 1, &flags);
                         if (rt >= 0.) {
                             ev_found = true;
@@ -790,7 +840,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                     double g[P + 1];
                     ev_poly_order<P, 0>::run(t, g, prm.re_k[0], prm.re_k[1], prm.re_k[2]);
                     g[0] -= prm.re_c0;
-                    if (!fex_excluded<P>(g, h)) {
+                    if (!fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
                         const double rt = event_first_root<P>(g, h, -1, &flags);
                         if (rt >= 0. && (!ev_found || rt < ev_t)) {
                             ev_found = true;

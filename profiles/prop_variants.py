@@ -26,5 +26,5 @@ for kind, C, recs, rr in [("j2drag", 8, True, True), ("j2drag", 8, False, True),
     step()
     step()
     prof = ctx.profile_get()
-    print(json.dumps(dict(kind=kind, C=C, recs=recs, reentry=rr, outcomes=oc, substeps=s.last_total_substeps, k_propagate=round(prof["k_propagate"][1] / 2, 3), k_store=round(prof["k_propagate_store"][1] / 2, 3))), flush=True)
+    print(json.dumps(dict(kind=kind, C=C, recs=recs, reentry=rr, outcomes=oc, substeps=s.last_total_substeps, k_propagate=round(prof.get("k_propagate", (0, 0))[1] / 2, 3), k_rows=round(prof.get("k_propagate_rows", (0, 0))[1] / 2, 3), k_store=round(prof.get("k_propagate_store", (0, 0))[1] / 2, 3))), flush=True)
     del s
