@@ -101,6 +101,7 @@ SYMBOLS = {
     "csc_timer_begin": (_i32, [_vp]),
     "csc_timer_end": (_i32, [_vp, C.POINTER(C.c_float)]),
     "csc_profile_enable": (_i32, [_vp, _i32]),
+    "csc_profile_only": (_i32, [_vp, C.c_char_p]),
     "csc_profile_reset": (_i32, [_vp]),
     "csc_profile_get": (_i32, [_vp, C.c_char_p, _sz]),
     "csc_propagate": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 10),
@@ -218,6 +219,10 @@ class Context:
 
     def profile(self, on=True):
         self._chk(self.L.csc_profile_enable(self.h, 1 if on else 0))
+
+    def profile_only(self, name=None):
+        """Time only the kernel `name` (None: all)."""
+        self._chk(self.L.csc_profile_only(self.h, name.encode() if name else None))
 
     def profile_reset(self):
         self._chk(self.L.csc_profile_reset(self.h))

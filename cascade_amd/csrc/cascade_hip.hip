@@ -84,10 +84,11 @@ struct csc_ctx {
     };
     std::map<std::string, ktimer> kt;
     bool profiling = false;
+    std::string profile_only; // when not empty: only this kernel is timed
     std::vector<csc_tape_op> tape_host; // the tape currently in the "tape_ops" buffer
     void kt_begin(const char *name)
     {
-        if (!profiling) {
+        if (!profiling || (!profile_only.empty() && profile_only != name)) {
             return;
         }
         auto &t = kt[name];
@@ -101,7 +102,7 @@ struct csc_ctx {
     }
     void kt_end(const char *name)
     {
-        if (!profiling) {
+        if (!profiling || (!profile_only.empty() && profile_only != name)) {
             return;
         }
         auto &t = kt[name];
@@ -623,6 +624,13 @@ int csc_profile_enable(csc_ctx *ctx, int on)
 {
     ctx->kt_collect();
     ctx->profiling = on != 0;
+    return CSC_OK;
+}
+
+int csc_profile_only(csc_ctx *ctx, const char *name)
+{
+    ctx->kt_collect();
+    ctx->profile_only = name ? name : "";
     return CSC_OK;
 }
 

@@ -179,6 +179,10 @@ int csc_timer_end(csc_ctx *ctx, float *ms);
  * src/sim_propagate.cpp:510,1123,1340). csc_profile_get synchronises and writes one line per
  * kernel, "name launches total_ms", into buf. */
 int csc_profile_enable(csc_ctx *ctx, int on);
+/* Restricts the timing to one kernel (NULL or "": all of them). Two event records around every
+ * launch cost ~8 us each way on the stream: with ~100 launches per superstep that is 0.8 ms, so
+ * a measurement of whole supersteps times only the kernel it reports. */
+int csc_profile_only(csc_ctx *ctx, const char *name);
 int csc_profile_reset(csc_ctx *ctx);
 int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap);
 
