@@ -129,6 +129,7 @@ SYMBOLS = {
     "csc_dense_propagate": (_i32, [_vp, _u32, _u32, _dbl] + [_vp] * 6),
     "csc_copy_final_state": (_i32, [_vp, _u32, _vp, _vp]),
     "csc_activity_flags": (_i32, [_vp, _u32, _vp, _dbl, _i32, _vp, _u64, _vp, _u64, _vp]),
+    "csc_remove_particles": (_i32, [_vp, _u32, _vp, _u64, _vp, _u32, _vp, _vp]),
 }
 
 

@@ -301,6 +301,32 @@ __global__ __launch_bounds__(256) void k_conj_gather(uint32_t n, const uint4 *sr
     dst[t] = src[static_cast<uint64_t>(idx[rec]) * 8u + (t & 7u)];
 }
 
+// Row compaction for the removal of particles: the row of particle i moves up by the number of
+// removed indices below i (binary search in the sorted list), removed rows are dropped. One
+// thread per element, src and dst distinct.
+__global__ __launch_bounds__(256) void k_remove_rows(uint32_t n, uint32_t width, const uint32_t *idx, uint32_t nidx,
+                                                      const double *src, double *dst)
+{
+    const uint64_t t = blockIdx.x * 256ull + threadIdx.x;
+    if (t >= static_cast<uint64_t>(n) * width) {
+        return;
+    }
+    const uint32_t i = static_cast<uint32_t>(t / width), c = static_cast<uint32_t>(t % width);
+    uint32_t lo = 0, hi = nidx;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (idx[mid] < i) {
+            lo = mid + 1u;
+        } else {
+            hi = mid;
+        }
+    }
+    if (lo < nidx && idx[lo] == i) {
+        return;
+    }
+    dst[static_cast<uint64_t>(i - lo) * width + c] = src[t];
+}
+
 __global__ __launch_bounds__(256) void k_copy_final_state(uint32_t n, const double *fs, double *state)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1753,6 +1779,47 @@ int csc_activity_flags(csc_ctx *ctx, uint32_t n, const double *d_state, double m
     KT("k_activity", hipLaunchKernelGGL(k_activity, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_state, min_coll_radius,
                        with_conj, n_coll_wl == 0 ? 1 : 0, n_conj_wl == 0 ? 1 : 0, d_mask, d_active));
     CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_remove_particles(csc_ctx *ctx, uint32_t n, const uint64_t *idx, uint64_t n_idx, double *d_state, uint32_t npars,
+                         double *d_pars, uint32_t *n_out)
+{
+    for (uint64_t k = 0; k < n_idx; ++k) {
+        if (idx[k] >= n || (k && idx[k] <= idx[k - 1])) {
+            ctx->err = "csc_remove_particles: the indices must be sorted, unique and smaller than n";
+            return CSC_ERR_INVALID;
+        }
+    }
+    if (n_out) {
+        *n_out = n - static_cast<uint32_t>(n_idx);
+    }
+    if (n_idx == 0 || n == 0) {
+        return CSC_OK;
+    }
+    const uint32_t keep = n - static_cast<uint32_t>(n_idx);
+    std::vector<uint32_t> idx32(idx, idx + n_idx);
+    CSC_BUF(d_idx, uint32_t, "rm_idx", n_idx);
+    CSC_HIP(hipMemcpyAsync(d_idx, idx32.data(), n_idx * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t wmax = std::max(7u, npars);
+    CSC_BUF(d_tmp, double, "rm_tmp", static_cast<uint64_t>(std::max(keep, 1u)) * wmax);
+    auto compact = [&](double *d_rows, uint32_t width) -> int {
+        KT("k_remove_rows", hipLaunchKernelGGL(k_remove_rows, dim3(cdiv(static_cast<uint64_t>(n) * width, 256)), dim3(256), 0,
+                           ctx->stream, n, width, d_idx, static_cast<uint32_t>(n_idx), d_rows, d_tmp));
+        CSC_LAUNCH_CHECK();
+        CSC_HIP(hipMemcpyAsync(d_rows, d_tmp, static_cast<uint64_t>(keep) * width * sizeof(double), hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        return CSC_OK;
+    };
+    if (int rc = compact(d_state, 7u)) {
+        return rc;
+    }
+    if (npars != 0u && d_pars != nullptr) {
+        if (int rc = compact(d_pars, npars)) {
+            return rc;
+        }
+    }
+    CSC_HIP(hipStreamSynchronize(ctx->stream)); // idx32 is pageable host memory
     return CSC_OK;
 }
 

@@ -319,6 +319,10 @@ struct sim::sim_data {
     int device = 0;
     dfloat time;
     bool host_sync = true, np_prefilter = true;
+    // With host_sync off the device copies of state and pars are the authoritative ones between
+    // steps: dev_rows = number of particles they hold, -1 = stale (never uploaded, or the host
+    // vectors were replaced by set_new_state_pars).
+    std::int64_t dev_rows = -1;
     // Dense-output rows in one pass: 0 never, 1 for everything but plain Kepler (default), 2 always
     // (environment CASCADE_SINGLE_PASS, for measurements); row_hint = most substeps of one particle
     // in the previous superstep (valid for the same ct and n_par_ct).
@@ -721,9 +725,12 @@ void sim::set_new_state_pars(std::vector<double> new_state, std::vector<double> 
     auto ps = std::make_shared<std::vector<double>>(std::move(new_pars));
     m_state = std::move(st);
     m_pars = std::move(ps);
+    m_data->dev_rows = -1;
 }
 
-// src/sim_basic.cpp:280-338
+// src/sim_basic.cpp:280-338. With the state resident on the device (host_sync off) the device
+// copies are compacted there (csc_remove_particles); the host vectors are always edited, so
+// their shapes, the sizes and the views handed out stay what the reference's are.
 void sim::remove_particles(std::vector<size_type> idxs)
 {
     std::sort(idxs.begin(), idxs.end());
@@ -732,6 +739,13 @@ void sim::remove_particles(std::vector<size_type> idxs)
     if (!idxs.empty() && idxs.back() >= nparts) {
         throw std::invalid_argument("An invalid vector of indices was passed to the function for particle removal: "
                                     + fmt_list(idxs));
+    }
+    if (auto &d = *m_data; !d.host_sync && d.ctx != nullptr && d.dev_rows == static_cast<std::int64_t>(nparts)) {
+        const std::vector<std::uint64_t> idx64(idxs.begin(), idxs.end());
+        std::uint32_t n_out = 0;
+        d.chk(csc_remove_particles(d.ctx, static_cast<std::uint32_t>(nparts), idx64.data(), idx64.size(),
+                                   d.get<double>("state"), m_npars, m_npars ? d.get<double>("pars") : nullptr, &n_out));
+        d.dev_rows = n_out;
     }
     std::vector<double> new_state, new_pars;
     new_state.reserve((nparts - idxs.size()) * 7u);
@@ -763,7 +777,11 @@ int sim::get_device() const
 
 void sim::set_host_sync(bool v)
 {
-    m_data->host_sync = v;
+    auto &d = *m_data;
+    if (v && !d.host_sync && d.ctx != nullptr && d.dev_rows == static_cast<std::int64_t>(get_nparts())) {
+        download_state(); // the host vectors become the authoritative copy again
+    }
+    d.host_sync = v;
 }
 
 bool sim::get_host_sync() const
@@ -845,6 +863,11 @@ void sim::upload_state()
     if (n) {
         d.chk(csc_memcpy_h2d(d.ctx, d_state, m_state->data(), n * 7u * sizeof(double)));
     }
+    if (m_npars != 0u && n) {
+        double *d_pars = d.buf<double>("pars", n * m_npars);
+        d.chk(csc_memcpy_h2d(d.ctx, d_pars, m_pars->data(), n * m_npars * sizeof(double)));
+    }
+    d.dev_rows = static_cast<std::int64_t>(n);
 }
 
 void sim::download_state()
@@ -852,6 +875,9 @@ void sim::download_state()
     auto &d = *m_data;
     d.ensure_ctx();
     const auto n = get_nparts();
+    if (d.dev_rows != static_cast<std::int64_t>(n)) {
+        throw std::invalid_argument("download_state(): the device holds no state for the current particles");
+    }
     double *d_state = d.buf<double>("state", n * 7u);
     std::vector<double> tmp(n * 7u);
     if (n) {
@@ -927,7 +953,7 @@ outcome sim::step()
     d.ensure_ctx();
     csc_ctx *ctx = d.ctx;
 
-    if (d.host_sync) {
+    if (d.host_sync || d.dev_rows != static_cast<std::int64_t>(nparts)) {
         // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
         for (size_type i = 0; i < nparts; ++i) {
             const double sz = (*m_state)[i * 7u + 6u];
@@ -968,12 +994,8 @@ outcome sim::step()
     d.chk(csc_activity_flags(ctx, n, d_state, m_min_coll_radius, with_conj ? 1 : 0, cwl.data(), cwl.size(), jwl.data(),
                              jwl.size(), d_active));
 
-    // Runtime parameters (host vector is authoritative, like the state).
-    double *d_pars = nullptr;
-    if (m_npars != 0u) {
-        d_pars = d.buf<double>("pars", static_cast<std::size_t>(n) * m_npars);
-        d.chk(csc_memcpy_h2d(ctx, d_pars, m_pars->data(), static_cast<std::size_t>(n) * m_npars * sizeof(double)));
-    }
+    // Runtime parameters: uploaded with the state (upload_state).
+    double *d_pars = m_npars != 0u ? d.buf<double>("pars", static_cast<std::size_t>(n) * m_npars) : nullptr;
 
     csc_prop_cfg cfg{};
     cfg.dyn_kind = d.dyn.kind;

@@ -362,7 +362,11 @@ public:
     [[nodiscard]] int get_device() const;
     // The host state is the source of truth at every step() entry and exit (the Python bindings
     // hand out writable views of it, cascade.py/core.cpp:199-230). With host_sync off the state
-    // stays resident in HBM between steps: upload_state() once, download_state() when needed.
+    // and the parameters stay resident in HBM between steps: they are uploaded by the first
+    // step() (or upload_state()) and again after set_new_state_pars(); remove_particles()
+    // compacts the device copies in place (csc_remove_particles); download_state() refreshes the
+    // host coordinates when they are needed; switching host_sync back on does it too. Edits of
+    // the host views are not seen by the device while host_sync is off (call upload_state()).
     void set_host_sync(bool);
     [[nodiscard]] bool get_host_sync() const;
     void upload_state();

@@ -346,6 +346,14 @@ int csc_activity_flags(csc_ctx *ctx, uint32_t n, const double *d_state, double m
                        const uint64_t *coll_wl, uint64_t n_coll_wl, const uint64_t *conj_wl, uint64_t n_conj_wl,
                        uint8_t *d_active);
 
+/* remove_particles (src/sim_basic.cpp:280-338) on the device copies: drops the rows idx[0..n_idx)
+ * (host array, sorted, unique, < n) from d_state [n][7] and, when npars != 0, d_pars [n][npars],
+ * keeping the order of the others; the compacted arrays hold *n_out = n - n_idx rows. For
+ * callers that keep the state resident between supersteps (the removal after each reentry or
+ * collision, benchmark/2022_leo_pop.cpp:311-337). Synchronous. */
+int csc_remove_particles(csc_ctx *ctx, uint32_t n, const uint64_t *idx, uint64_t n_idx, double *d_state, uint32_t npars,
+                         double *d_pars, uint32_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif
