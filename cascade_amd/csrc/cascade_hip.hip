@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1559,6 +1560,17 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
+        const bool tm = std::getenv("CASCADE_HOST_TIMERS") != nullptr;
+        auto tm0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (tm) {
+                const auto t1 = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[narrow] %-12s %9.3f ms (attempt %d)\n", what,
+                             std::chrono::duration<double, std::milli>(t1 - tm0).count(), attempt);
+                tm0 = t1;
+            }
+        };
+        lap("kernels");
         if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap && h[5] <= cand_cap) {
             ctx->np_candidates = h[5];
             ctx->coll.resize(h[0]);
@@ -1573,6 +1585,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                 ctx->conj_cap = want;
             }
             ctx->conj_count = h[1];
+            lap("pinned alloc");
             if (h[0]) {
                 CSC_HIP(hipMemcpyAsync(ctx->coll.data(), d_coll, h[0] * sizeof(csc::coll_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
@@ -1603,6 +1616,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                                        ctx->stream));
             }
             CSC_HIP(hipStreamSynchronize(ctx->stream));
+            lap("sort + d2h");
             // Deterministic container order: (time, i, j).
             std::sort(ctx->coll.begin(), ctx->coll.end(), [](const csc_collision &a, const csc_collision &b) {
                 return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
@@ -1625,6 +1639,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             } else if (ctx->conj_count) {
                 std::sort(ctx->conj, ctx->conj + ctx->conj_count, conj_less);
             }
+            lap("tie order");
             *n_coll = h[0];
             *n_conj = h[1];
             if (warn_flags) {

@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +22,9 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
+
+#include <sys/mman.h>
 
 #include <cascade/sim.hpp>
 #include <cascade_hip.h>
@@ -292,6 +297,53 @@ dfloat df_sub(dfloat x, dfloat y)
 bool df_lt(dfloat a, dfloat b)
 {
     return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
+}
+
+// CASCADE_HOST_TIMERS=1: wall time of the phases of step() on stderr (measurements only).
+struct phase_timer {
+    bool on = std::getenv("CASCADE_HOST_TIMERS") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (on) {
+            const auto t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[step] %-12s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
+    }
+};
+
+// First touch of a large stretch of freshly reserved (not yet constructed) vector storage by
+// several threads: a conjunction-heavy superstep appends gigabytes of records, and a single
+// thread faulting the pages in while it copies runs at a fraction of the memory bandwidth.
+void prefault(void *p, std::size_t bytes)
+{
+    constexpr std::size_t page = 4096;
+    if (bytes < (64u << 20)) {
+        return;
+    }
+    auto lo = (reinterpret_cast<std::uintptr_t>(p) + page - 1) / page * page;
+    const auto hi = (reinterpret_cast<std::uintptr_t>(p) + bytes) / page * page;
+    if (hi <= lo) {
+        return;
+    }
+    (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const std::size_t per = ((hi - lo) / page + nt - 1) / nt * page;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        const auto b = lo + t * per, e = std::min<std::uintptr_t>(hi, b + per);
+        if (b < e) {
+            th.emplace_back([b, e] {
+                for (auto a = b; a < e; a += page) {
+                    *reinterpret_cast<volatile char *>(a) = 0;
+                }
+            });
+        }
+    }
+    for (auto &t : th) {
+        t.join();
+    }
 }
 
 bool df_eq(dfloat a, dfloat b)
@@ -878,15 +930,10 @@ void sim::download_state()
     if (d.dev_rows != static_cast<std::int64_t>(n)) {
         throw std::invalid_argument("download_state(): the device holds no state for the current particles");
     }
-    double *d_state = d.buf<double>("state", n * 7u);
-    std::vector<double> tmp(n * 7u);
+    // One copy of the whole [n][7] array: the sizes on the device are the host's as of the last
+    // upload (only the six coordinates are outputs of a step, copy_from_final_state :1610-1630).
     if (n) {
-        d.chk(csc_memcpy_d2h(d.ctx, tmp.data(), d_state, n * 7u * sizeof(double)));
-    }
-    // Only the six coordinates are outputs of a step (copy_from_final_state, :1610-1630); the
-    // sizes stay the host's.
-    for (size_type i = 0; i < n; ++i) {
-        std::copy(tmp.begin() + i * 7u, tmp.begin() + i * 7u + 6u, m_state->begin() + i * 7u);
+        d.chk(csc_memcpy_d2h(d.ctx, m_state->data(), d.buf<double>("state", n * 7u), n * 7u * sizeof(double)));
     }
 }
 
@@ -902,8 +949,11 @@ void sim::append_conj_data(const void *recs, std::size_t n)
     if (m_det_conj->size() + n > m_det_conj->capacity()) {
         auto nv = std::make_shared<std::vector<conjunction>>();
         nv->reserve(2u * (m_det_conj->size() + n));
+        prefault(nv->data(), (m_det_conj->size() + n) * sizeof(conjunction));
         nv->insert(nv->end(), m_det_conj->begin(), m_det_conj->end());
         m_det_conj = std::move(nv);
+    } else {
+        prefault(m_det_conj->data() + m_det_conj->size(), n * sizeof(conjunction));
     }
     const auto *src = static_cast<const conjunction *>(recs);
     m_det_conj->insert(m_det_conj->end(), src, src + n);
@@ -952,6 +1002,7 @@ outcome sim::step()
     }
     d.ensure_ctx();
     csc_ctx *ctx = d.ctx;
+    phase_timer pt;
 
     if (d.host_sync || d.dev_rows != static_cast<std::int64_t>(nparts)) {
         // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
@@ -1072,6 +1123,7 @@ outcome sim::step()
     }
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+    pt.lap("propagate");
     d.row_hint = summ.max_substeps;
     d.row_hint_ct = m_ct;
     d.row_hint_nchunks = nchunks0;
@@ -1130,6 +1182,7 @@ outcome sim::step()
         }
         d.chk(rc);
     }
+    pt.lap("sort/bvh/bp");
     std::uint64_t ncoll = 0, nconj = 0;
     std::uint32_t warn = 0;
     d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
@@ -1140,6 +1193,7 @@ outcome sim::step()
     const csc_conjunction *conj_p = nullptr;
     std::uint64_t ncoll_v = 0, nconj_v = 0;
     d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
+    pt.lap("narrow");
 
     d.stats.bp_pairs = npairs;
     d.stats.bp_node_pairs = csc_broad_phase_node_pairs(ctx);
@@ -1197,10 +1251,13 @@ outcome sim::step()
             download_state();
         }
         m_int_info.reset();
+        pt.lap("final state");
         if (with_conj) {
             append_conj_data(conj_p, nconj_v);
         }
+        pt.lap("append conj");
     } else {
+        pt.lap("outcome");
         dense_propagate(interrupt_time);
         d.time = df_add(d.time, dfloat{interrupt_time, 0.});
         if (oc == outcome::collision) {
