@@ -76,6 +76,8 @@ struct csc_ctx {
     csc_conjunction *conj = nullptr;
     size_t conj_cap = 0, conj_count = 0;
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
+    // CASCADE_NP_CONJ_FAST=0: conjunction searches through the general root isolation only (tests).
+    bool np_conj_fast = std::getenv("CASCADE_NP_CONJ_FAST") == nullptr || std::atoi(std::getenv("CASCADE_NP_CONJ_FAST")) != 0;
     // per-kernel HIP-event timing (csc_profile_*)
     struct ktimer {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
@@ -1499,6 +1501,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         q.init_lo = init_time_lo;
         q.conj_thresh2 = conj_thresh * conj_thresh;
         q.thr_extra = conj_thresh;
+        q.conj_fast = ctx->np_conj_fast ? 1 : 0;
         q.state = d_state;
         q.active = d_active;
         q.tc_row = d_tc_row;
@@ -1571,6 +1574,10 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             }
         };
         lap("kernels");
+        if (tm) {
+            std::fprintf(stderr, "[narrow] counters: coll %u conj %u warn %u surv %u defer %u cand %u c6 %u c7 %u\n", h[0], h[1], h[2],
+                         h[3], h[4], h[5], h[6], h[7]);
+        }
         if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap && h[5] <= cand_cap) {
             ctx->np_candidates = h[5];
             ctx->coll.resize(h[0]);

@@ -230,6 +230,23 @@ CSC_DEV bool fex_excluded(const double *cf, double h)
     return s_lo == s_hi && s_lo != 0;
 }
 
+// Slot in an output list for every lane that is active at the call, with ONE atomic per wave:
+// the first active lane adds the number of active lanes to the counter. For appends in divergent
+// code whose counter pointer the compiler cannot prove uniform (behind a reference in an
+// out-of-line function): there it issues one atomic per lane, and ~10^7 atomics on one address
+// take ~13 ns each -- longer than all the arithmetic of a conjunction-heavy narrow phase.
+CSC_DEV std::uint32_t wave_append_slot(std::uint32_t *counter)
+{
+    const unsigned long long active = __ballot(1);
+    const unsigned lane = __lane_id();
+    std::uint32_t base = 0;
+    if (lane == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1)) {
+        base = atomicAdd(counter, static_cast<std::uint32_t>(__popcll(active)));
+    }
+    base = static_cast<std::uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+    return base + static_cast<std::uint32_t>(__popcll(active & ((1ull << lane) - 1ull)));
+}
+
 // ---------------------------------------------------------------------------
 // Scalar polynomial helpers (runtime order; operate on arrays in private memory).
 // ---------------------------------------------------------------------------
@@ -247,6 +264,34 @@ __device__ inline double poly_eval_1(const double *a, double x, int n)
     double ret1 = a[n] * n;
     for (int i = 1; i < n; ++i) {
         ret1 = a[n - i] * (n - i) + ret1 * x;
+    }
+    return ret1;
+}
+
+// The same two evaluations with the order known at compile time (N > 0): fully unrolled, the
+// coefficients stay in registers; N == 0 = runtime order n. Same operations in the same order.
+template <int N>
+__device__ __forceinline__ double poly_eval_n(const double *a, double x, int n)
+{
+    if constexpr (N > 0) {
+        double ret = a[N];
+#pragma unroll
+        for (int i = 1; i <= N; ++i) {
+            ret = a[N - i] + ret * x;
+        }
+        return ret;
+    } else {
+        return poly_eval(a, x, n);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ double poly_eval_1_n(const double *a, double x)
+{
+    double ret1 = a[N] * N;
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        ret1 = a[N - i] * (N - i) + ret1 * x;
     }
     return ret1;
 }
@@ -371,7 +416,8 @@ __device__ inline double safe_div(double num, double denom, double r)
     return num / denom;
 }
 
-__device__ inline void bracket(const double *p, int n, double &a, double &b, double c, double &fa, double &fb,
+template <int N = 0>
+__device__ __forceinline__ void bracket(const double *p, int n, double &a, double &b, double c, double &fa, double &fb,
                                double &d, double &fd)
 {
     const double tol = DBL_EPSILON * 2;
@@ -382,7 +428,7 @@ __device__ inline void bracket(const double *p, int n, double &a, double &b, dou
     } else if (c >= b - fabs(b) * tol) {
         c = b - fabs(b) * tol;
     }
-    const double fc = poly_eval(p, c, n);
+    const double fc = poly_eval_n<N>(p, c, n);
     if (fc == 0) {
         a = c;
         fa = 0;
@@ -453,11 +499,12 @@ __device__ inline double cubic_interpolate(double a, double b, double d, double 
 
 // Returns an error flag (non-zero = domain error); [a, b] is the final bracket and
 // used the number of iterations charged (incl. the two end-point evaluations).
-__device__ inline int solve(const double *p, int n, double ax, double bx, double &a_out, double &b_out, int &used)
+template <int N = 0>
+__device__ __forceinline__ int solve(const double *p, int n, double ax, double bx, double &a_out, double &b_out, int &used)
 {
     const int limit = 100;
     int max_iter = limit - 2;
-    const double fax = poly_eval(p, ax, n), fbx = poly_eval(p, bx, n);
+    const double fax = poly_eval_n<N>(p, ax, n), fbx = poly_eval_n<N>(p, bx, n);
     int count = max_iter;
     double a = ax, b = bx, fa = fax, fb = fbx, c, u, fu, a0, b0, d, fd, e, fe;
     const double mu = 0.5;
@@ -486,13 +533,13 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
 
     if (fa != 0) {
         c = secant_interpolate(a, b, fa, fb);
-        bracket(p, n, a, b, c, fa, fb, d, fd);
+        bracket<N>(p, n, a, b, c, fa, fb, d, fd);
         --count;
         if (count && (fa != 0) && !tol_eps(a, b)) {
             c = quadratic_interpolate(a, b, d, fa, fb, fd, 2);
             e = d;
             fe = fd;
-            bracket(p, n, a, b, c, fa, fb, d, fd);
+            bracket<N>(p, n, a, b, c, fa, fb, d, fd);
             --count;
         }
     }
@@ -510,7 +557,7 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
         }
         e = d;
         fe = fd;
-        bracket(p, n, a, b, c, fa, fb, d, fd);
+        bracket<N>(p, n, a, b, c, fa, fb, d, fd);
         if ((0 == --count) || (fa == 0) || tol_eps(a, b)) {
             break;
         }
@@ -521,7 +568,7 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
         } else {
             c = cubic_interpolate(a, b, d, e, fa, fb, fd, fe);
         }
-        bracket(p, n, a, b, c, fa, fb, d, fd);
+        bracket<N>(p, n, a, b, c, fa, fb, d, fd);
         if ((0 == --count) || (fa == 0) || tol_eps(a, b)) {
             break;
         }
@@ -538,7 +585,7 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
         }
         e = d;
         fe = fd;
-        bracket(p, n, a, b, c, fa, fb, d, fd);
+        bracket<N>(p, n, a, b, c, fa, fb, d, fd);
         if ((0 == --count) || (fa == 0) || tol_eps(a, b)) {
             break;
         }
@@ -547,7 +594,7 @@ __device__ inline int solve(const double *p, int n, double ax, double bx, double
         }
         e = d;
         fe = fd;
-        bracket(p, n, a, b, a + (b - a) / 2, fa, fb, d, fd);
+        bracket<N>(p, n, a, b, a + (b - a) / 2, fa, fb, d, fd);
         --count;
     }
     max_iter -= count;
@@ -745,6 +792,222 @@ __device__ inline int isolate_and_refine(const double *poly, int order, double r
             double a, b;
             int used;
             const int err = t748::solve(root_poly, order, lo, up, a, b, used);
+            if (err != 0 || !(used < 100)) {
+                *warn |= 8;
+                continue;
+            }
+            add_root(((a + b) / 2) * rf_int);
+        }
+    }
+    return loop_failed ? -1 - n_roots : n_roots;
+}
+
+template <int N>
+__device__ __forceinline__ void poly_rescale_n(double *ret, const double *a, double scal)
+{
+    double cur_f = 1;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        ret[i] = cur_f * a[i];
+        cur_f *= scal;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void poly_rescale_p2_n(double *ret, const double *a)
+{
+    double cur_f = 1;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        ret[N - i] = cur_f * a[N - i];
+        cur_f *= 2;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void poly_translate_1_n(double *ret, const double *cf)
+{
+    constexpr binom_tab bt = make_binom_tab();
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        double acc = cf[i];
+#pragma unroll
+        for (int k = i + 1; k <= N; ++k) {
+            acc += bt.v[k * BINOM_N + i] * cf[k];
+        }
+        ret[i] = acc;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ int poly_rtscc_n(double *out1, double *out2, const double *cf)
+{
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        out1[i] = cf[N - i];
+    }
+    poly_translate_1_n<N>(out2, out1);
+    int count = 0, last = 0;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        const int s = sgn(out2[i]);
+        if (s != 0) {
+            if (last != 0 && s != last) {
+                ++count;
+            }
+            last = s;
+        }
+    }
+    return count;
+}
+
+// The same search with the order known at compile time: every coefficient loop is unrolled, so
+// the polynomials (root_poly, tmp, tmp1, tmp2 and the caller's poly) live in registers instead
+// of private memory, where each access of the runtime-order version above is a scratch round
+// trip and a translation by 1 costs ~10^5 cycles. Statement for statement the function above
+// (kept as the general fallback and as the comparison in the tests): same operations, same
+// order, same bits.
+template <int N>
+__device__ __forceinline__ int isolate_and_refine_n(const double *poly, double rf_int, int direction, double *roots,
+                                                    int max_roots, int *warn)
+{
+    constexpr int order = N;
+    double root_poly[N + 1]; // poly rescaled to [0, 1)
+    double tmp[N + 1], tmp1[N + 1], tmp2[N + 1];
+    double isol_lb[N + 1], isol_ub[N + 1];
+    int n_isol = 0, n_roots = 0;
+
+    auto add_root = [&](double root) {
+        if (!finite_d(root)) {
+            *warn |= 1;
+            return;
+        }
+        if (direction != 0) {
+            const double der = poly_eval_1_n<N>(poly, root);
+            if (!finite_d(der)) {
+                *warn |= 1;
+                return;
+            }
+            if (sgn(der) != direction) {
+                return;
+            }
+        }
+        if (n_roots < max_roots) {
+            roots[n_roots] = root;
+        } else {
+            *warn |= 2;
+        }
+        ++n_roots;
+    };
+
+    poly_rescale_n<N>(root_poly, poly, rf_int);
+#pragma unroll
+    for (int i = 0; i <= order; ++i) {
+        tmp[i] = root_poly[i];
+    }
+
+    rf_path path;
+    path.clear();
+    int depth = 0;       // depth of the current node (root = 0)
+    int n_pending = 0;   // == wlist.size() after popping the current node
+    double lb = 0., ub = 1.;
+    bool loop_failed = false;
+
+    while (true) {
+        // --- process the current node (tmp, [lb, ub)) ---
+        if (tmp[0] == 0) {
+            bool all_fin = true;
+#pragma unroll
+            for (int i = 1; i <= order; ++i) {
+                all_fin = all_fin && finite_d(tmp[i]);
+            }
+            if (all_fin) {
+                add_root(lb * rf_int);
+            }
+        }
+        const int n_sc = poly_rtscc_n<N>(tmp1, tmp2, tmp);
+        bool descend = false;
+        if (n_sc == 1) {
+            if (n_isol <= order) {
+                isol_lb[n_isol] = lb;
+                isol_ub[n_isol] = ub;
+            }
+            ++n_isol;
+        } else if (n_sc > 1) {
+            descend = true;
+            n_pending += 2;
+        }
+        // NOTE: the depth guard has no counterpart in the reference (whose work-list holds the
+        // polynomials themselves); it only bounds the path word and cannot trigger before an
+        // interval has been halved ~1100 times, i.e. far past double precision.
+        if (n_pending > 250 || n_isol > order || depth >= RF_MAX_DEPTH) {
+            *warn |= 4;
+            loop_failed = true;
+            break;
+        }
+        if (descend) {
+            // Next node = right child: 2^n q((x + 1) / 2).
+            poly_rescale_p2_n<N>(tmp1, tmp);
+            poly_translate_1_n<N>(tmp2, tmp1);
+#pragma unroll
+            for (int i = 0; i <= order; ++i) {
+                tmp[i] = tmp2[i];
+            }
+            const double mid = (lb + ub) / 2;
+            lb = mid;
+            path.set(depth, true);
+            ++depth;
+            --n_pending; // popped the right child
+            continue;
+        }
+        if (n_pending == 0) {
+            break;
+        }
+        // Pop the deepest pending left sibling: find the deepest right-turn.
+        int k = depth - 1;
+        while (k >= 0 && !path.get(k)) {
+            --k;
+        }
+        // k >= 0 is guaranteed by n_pending > 0.
+        path.set(k, false);
+        depth = k + 1;
+        --n_pending;
+        // Replay from the root along path[0 .. depth).
+#pragma unroll
+        for (int i = 0; i <= order; ++i) {
+            tmp[i] = root_poly[i];
+        }
+        lb = 0.;
+        ub = 1.;
+        for (int lvl = 0; lvl < depth; ++lvl) {
+            const double mid = (lb + ub) / 2;
+            poly_rescale_p2_n<N>(tmp1, tmp);
+            if (path.get(lvl)) {
+                poly_translate_1_n<N>(tmp2, tmp1);
+#pragma unroll
+                for (int i = 0; i <= order; ++i) {
+                    tmp[i] = tmp2[i];
+                }
+                lb = mid;
+            } else {
+#pragma unroll
+                for (int i = 0; i <= order; ++i) {
+                    tmp[i] = tmp1[i];
+                }
+                ub = mid;
+            }
+        }
+    }
+
+    if (n_isol > 0 && !loop_failed) {
+        for (int k = 0; k < n_isol; ++k) {
+            double lo = isol_lb[k], up = isol_ub[k];
+            if (finite_d(lo) && finite_d(up) && up > lo) {
+                up = nextafter(up, lo);
+            }
+            double a, b;
+            int used;
+            const int err = t748::solve<N>(root_poly, order, lo, up, a, b, used);
             if (err != 0 || !(used < 100)) {
                 *warn |= 8;
                 continue;

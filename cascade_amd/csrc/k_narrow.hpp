@@ -70,6 +70,7 @@ struct np_params {
     const std::uint32_t *vidx;    // [C][n] sorted position -> original index
     const float4 *srt_recs;       // [C][n][4] sampled-trajectory records in sorted order
     double thr_extra;             // conjunction threshold (0 when conjunctions are not tracked)
+    int conj_fast;                // root searches with the polynomials in registers (np_slow_path_regs)
     // candidates: pairs that survive the pre-filter, {pi, pj, chunk, 0} with ORIGINAL indices
     uint4 *cand;
     std::uint32_t cand_cap;
@@ -249,7 +250,7 @@ CSC_DEV_NOINLINE void np_slow_path(const np_params &q, const double *ss_in, bool
                 warn |= 1;
                 continue;
             }
-            const std::uint32_t slot = atomicAdd(&q.counters[0], 1u);
+            const std::uint32_t slot = wave_append_slot(&q.counters[0]);
             if (slot < q.coll_cap) {
                 q.coll[slot] = coll_rec{pi, pj, tcoll};
             }
@@ -291,9 +292,119 @@ CSC_DEV_NOINLINE void np_slow_path(const np_params &q, const double *ss_in, bool
                     load_poly_rt(poly, q.tcs_xyz, q.tcs_vr, row_j, cc, delta_j, P);
                     c.state_j[cc] = poly_eval(poly, conj_tm, P);
                 }
-                const std::uint32_t slot = atomicAdd(&q.counters[1], 1u);
+                const std::uint32_t slot = wave_append_slot(&q.counters[1]);
                 if (slot < q.conj_cap) {
                     q.conj[slot] = c;
+                }
+            }
+        }
+    }
+    if (warn) {
+        atomicOr(&q.counters[2], static_cast<std::uint32_t>(warn));
+    }
+}
+
+// The record of a conjunction at conj_tm after the window start (src/sim_narrow_phase.cpp:886-947):
+// the twelve coordinates by Horner on the translated polynomials, in registers (same operations
+// as load_poly_rt + poly_eval).
+template <int P>
+CSC_DEV void np_conj_write(const np_params &q, conj_rec *out, double conj_tm, double conj_dist2, dfl lb_rf,
+                           std::uint32_t pi, std::uint32_t pj, std::uint64_t row_i, std::uint64_t row_j, double delta_i,
+                           double delta_j)
+{
+    out->i = pi;
+    out->j = pj;
+    const dfl init_time{q.init_hi, q.init_lo};
+    out->time = df_add(init_time, df_add(lb_rf, df(conj_tm))).hi;
+    out->dist = sqrt(dmax(conj_dist2, 0.));
+    const double *xi = q.tcs_xyz + row_i * static_cast<std::uint64_t>(tc_xyz_stride(P));
+    const double *xj = q.tcs_xyz + row_j * static_cast<std::uint64_t>(tc_xyz_stride(P));
+    const double *vi = q.tcs_vr + row_i * static_cast<std::uint64_t>(tc_vr_stride(P));
+    const double *vj = q.tcs_vr + row_j * static_cast<std::uint64_t>(tc_vr_stride(P));
+#pragma unroll 1
+    for (int cc = 0; cc < 12; ++cc) {
+        const int c6 = cc >> 1;
+        const bool second = (cc & 1) != 0;
+        const double *src = (c6 < 3) ? (second ? xj : xi) + c6 * (P + 1) : (second ? vj : vi) + (c6 - 3) * (P + 1);
+        const double delta = second ? delta_j : delta_i;
+        double raw[P + 1], poly[P + 1];
+#pragma unroll
+        for (int o = 0; o <= P; ++o) {
+            raw[o] = src[o];
+        }
+        if (delta != 0.) {
+            translate_a_regs<P>(poly, raw, delta);
+        } else {
+#pragma unroll
+            for (int o = 0; o <= P; ++o) {
+                poly[o] = raw[o];
+            }
+        }
+        const double v = poly_eval_n<P>(poly, conj_tm, P);
+        (second ? out->state_j : out->state_i)[c6] = v;
+    }
+}
+
+// np_slow_path with the polynomials in registers (isolate_and_refine_n, np_conj_write): the
+// same operations in the same order, hence the same events bit for bit, at ~1/40 of the time --
+// in a conjunction-heavy superstep nearly every candidate pair gets here.
+template <int P>
+CSC_DEV_NOINLINE void np_slow_path_regs(const np_params &q, const double *ss_in, bool do_coll, bool do_conj, double rsum2,
+                                        double rf_int, dfl lb_rf, std::uint32_t pi, std::uint32_t pj, std::uint64_t row_i,
+                                        std::uint64_t row_j, double delta_i, double delta_j)
+{
+    double ss[P + 1], roots[P + 1];
+#pragma unroll
+    for (int o = 0; o <= P; ++o) {
+        ss[o] = ss_in[o];
+    }
+    int warn = 0;
+    if (do_coll) {
+        const double c0 = ss[0];
+        ss[0] = c0 - rsum2;
+        int nr = isolate_and_refine_n<P>(ss, rf_int, -1, roots, P + 1, &warn);
+        if (nr < 0) {
+            nr = -1 - nr;
+        }
+        for (int k = 0; k < nr && k <= P; ++k) {
+            const double tcoll = df_add(lb_rf, df(roots[k])).hi;
+            if (!finite_d(tcoll)) {
+                warn |= 1;
+                continue;
+            }
+            const std::uint32_t slot = wave_append_slot(&q.counters[0]);
+            if (slot < q.coll_cap) {
+                q.coll[slot] = coll_rec{pi, pj, tcoll};
+            }
+        }
+        ss[0] = c0;
+    }
+    if (do_conj) {
+        double der[P + 1];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            der[i] = (i + 1) * ss[i + 1];
+        }
+        der[P] = 0;
+        int nr = isolate_and_refine_n<P>(der, rf_int, 1, roots, P + 1, &warn);
+        if (nr < 0) {
+            nr = -1 - nr;
+        }
+        for (int k = 0; k < nr && k <= P; ++k) {
+            const double conj_tm = df_add(df(0.), df(roots[k])).hi;
+            if (!finite_d(conj_tm)) {
+                warn |= 1;
+                continue;
+            }
+            const double conj_dist2 = poly_eval_n<P>(ss, conj_tm, P);
+            if (!finite_d(conj_dist2)) {
+                warn |= 1;
+                continue;
+            }
+            if (conj_dist2 < q.conj_thresh2) {
+                const std::uint32_t slot = wave_append_slot(&q.counters[1]);
+                if (slot < q.conj_cap) {
+                    np_conj_write<P>(q, q.conj + slot, conj_tm, conj_dist2, lb_rf, pi, pj, row_i, row_j, delta_i, delta_j);
                 }
             }
         }
@@ -616,8 +727,15 @@ __global__ __launch_bounds__(64) void k_np_roots(const np_params q)
     const double rsum2 = np_rsum2(q, pi, pj);
     double ss[P + 1];
     np_build_ss<P>(ss, q.tcs_xyz, off_i + r1.x, off_j + r1.y, w.delta_i, w.delta_j);
-    np_slow_path<P>(q, ss, (r0.w & 1u) != 0, (r0.w & 2u) != 0, rsum2, w.rf_int, w.lb_rf, pi, pj, off_i + r1.x,
-                    off_j + r1.y, w.delta_i, w.delta_j);
+    const bool do_coll = (r0.w & 1u) != 0;
+    const bool do_conj = (r0.w & 2u) != 0;
+    if (q.conj_fast) {
+        np_slow_path_regs<P>(q, ss, do_coll, do_conj, rsum2, w.rf_int, w.lb_rf, pi, pj, off_i + r1.x, off_j + r1.y, w.delta_i,
+                             w.delta_j);
+    } else {
+        np_slow_path<P>(q, ss, do_coll, do_conj, rsum2, w.rf_int, w.lb_rf, pi, pj, off_i + r1.x, off_j + r1.y, w.delta_i,
+                        w.delta_j);
+    }
 }
 
 // K8: dense_propagate (src/sim_propagate.cpp:1401-1500). out: [n][6].

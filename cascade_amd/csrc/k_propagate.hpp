@@ -628,11 +628,12 @@ template <int P>
 CSC_DEV_NOINLINE double event_first_root(const double *g_in, double h, int direction, int *warn)
 {
     double g[P + 1];
+#pragma unroll
     for (int i = 0; i <= P; ++i) {
         g[i] = g_in[i];
     }
     double roots[P + 1];
-    int n = isolate_and_refine(g, P, h, direction, roots, P + 1, warn);
+    int n = isolate_and_refine_n<P>(g, h, direction, roots, P + 1, warn);
     if (n < 0) {
         n = -1 - n;
     }
