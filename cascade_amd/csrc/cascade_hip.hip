@@ -293,6 +293,16 @@ __global__ __launch_bounds__(256) void k_conj_keys(uint32_t n, const csc::conj_r
     keys[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// Number of adjacent equal keys in a sorted list (records with equal times still need their
+// (i, j) order from the host; almost always there are none).
+__global__ __launch_bounds__(256) void k_count_ties(uint32_t n, const uint64_t *keys, uint32_t *count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1u < n && keys[i] == keys[i + 1u]) {
+        atomicAdd(count, 1u);
+    }
+}
+
 // dst[k] = src[idx[k]] for 128-byte records, 8 lanes per record (one 16-byte piece each).
 __global__ __launch_bounds__(256) void k_conj_gather(uint32_t n, const uint4 *src, const uint32_t *idx, uint4 *dst)
 {
@@ -1600,6 +1610,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             // Large conjunction lists are put in time order on the device (radix sort of the time
             // keys, gather of the 128-byte records); ties and small lists are ordered on the host.
             const bool dev_sorted = h[1] > 32768u;
+            uint32_t n_ties = 0;
             if (dev_sorted) {
                 const uint32_t nc = h[1];
                 CSC_BUF(d_ka, uint64_t, "conj_keys_a", nc);
@@ -1616,7 +1627,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                 KT("k_conj_gather", hipLaunchKernelGGL(k_conj_gather, dim3(cdiv(static_cast<uint64_t>(nc) * 8u, 256)), dim3(256), 0,
                                                         ctx->stream, nc, reinterpret_cast<const uint4 *>(d_conj), vres,
                                                         reinterpret_cast<uint4 *>(d_sorted)));
+                KT("k_count_ties", hipLaunchKernelGGL(k_count_ties, dim3(cdiv(nc, 256)), dim3(256), 0, ctx->stream, nc, kres, d_cnt + 7));
                 CSC_LAUNCH_CHECK();
+                CSC_HIP(hipMemcpyAsync(&n_ties, d_cnt + 7, sizeof(n_ties), hipMemcpyDeviceToHost, ctx->stream));
                 CSC_HIP(hipMemcpyAsync(ctx->conj, d_sorted, nc * sizeof(csc::conj_rec), hipMemcpyDeviceToHost, ctx->stream));
             } else if (h[1]) {
                 CSC_HIP(hipMemcpyAsync(ctx->conj, d_conj, h[1] * sizeof(csc::conj_rec), hipMemcpyDeviceToHost,
@@ -1631,7 +1644,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             const auto conj_less = [](const csc_conjunction &a, const csc_conjunction &b) {
                 return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
             };
-            if (dev_sorted) {
+            if (dev_sorted && n_ties == 0u) {
+                // in time order, all times distinct: nothing left to do
+            } else if (dev_sorted) {
                 // Already in time order: only runs of equal times need (i, j) order.
                 for (size_t b0 = 0; b0 < ctx->conj_count;) {
                     size_t e0 = b0 + 1;

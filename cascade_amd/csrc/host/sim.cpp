@@ -375,6 +375,9 @@ struct sim::sim_data {
     // steps: dev_rows = number of particles they hold, -1 = stale (never uploaded, or the host
     // vectors were replaced by set_new_state_pars).
     std::int64_t dev_rows = -1;
+    // Inside propagate_until() nobody can touch the host vectors between the supersteps: the
+    // state goes up once (loop_uploaded) and comes down once, when the loop ends.
+    bool in_loop = false, loop_uploaded = false;
     // Dense-output rows in one pass: 0 never, 1 for everything but plain Kepler (default), 2 always
     // (environment CASCADE_SINGLE_PASS, for measurements); row_hint = most substeps of one particle
     // in the previous superstep (valid for the same ct and n_par_ct).
@@ -974,7 +977,7 @@ void sim::dense_propagate(double t)
     }
     d.chk(rc);
     d.chk(csc_copy_final_state(d.ctx, n, d.get<double>("final_state"), d.get<double>("state")));
-    if (d.host_sync) {
+    if (d.host_sync && !d.in_loop) {
         download_state();
     }
 }
@@ -1004,7 +1007,7 @@ outcome sim::step()
     csc_ctx *ctx = d.ctx;
     phase_timer pt;
 
-    if (d.host_sync || d.dev_rows != static_cast<std::int64_t>(nparts)) {
+    if ((d.host_sync && !(d.in_loop && d.loop_uploaded)) || d.dev_rows != static_cast<std::int64_t>(nparts)) {
         // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
         for (size_type i = 0; i < nparts; ++i) {
             const double sz = (*m_state)[i * 7u + 6u];
@@ -1014,6 +1017,7 @@ outcome sim::step()
             }
         }
         upload_state();
+        d.loop_uploaded = true;
     }
 
     const std::size_t cn = static_cast<std::size_t>(nchunks0) * n;
@@ -1247,7 +1251,7 @@ outcome sim::step()
     if (oc == outcome::success) {
         d.time = df_add(d.time, dfloat{delta_t0, 0.});
         d.chk(csc_copy_final_state(ctx, n, d_final, d_state));
-        if (d.host_sync) {
+        if (d.host_sync && !d.in_loop) {
             download_state();
         }
         m_int_info.reset();
@@ -1288,6 +1292,24 @@ outcome sim::propagate_until(double t)
     if (df_eq(final_t, d.time)) {
         return outcome::time_limit;
     }
+    // The host state is refreshed once, however the loop ends (an exception leaves the state of
+    // the last completed superstep, as a sequence of step() calls would).
+    struct loop_guard {
+        sim *s;
+        ~loop_guard()
+        {
+            auto &dd = *s->m_data;
+            dd.in_loop = false;
+            if (dd.host_sync && dd.loop_uploaded) {
+                try {
+                    s->download_state();
+                } catch (...) {
+                }
+            }
+        }
+    } guard{this};
+    d.in_loop = true;
+    d.loop_uploaded = false;
     while (true) {
         const dfloat orig_t = d.time;
         const outcome cur = step();
