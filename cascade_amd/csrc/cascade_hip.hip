@@ -76,6 +76,10 @@ struct csc_ctx {
     csc_conjunction *conj = nullptr;
     size_t conj_cap = 0, conj_count = 0;
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
+    // csc_narrow_phase_prefilter -> csc_narrow_phase_finish: the candidate list left on the device
+    const uint4 *np_cand_list = nullptr;
+    uint64_t np_cand_count = 0;
+    bool np_cand_valid = false;
     // CASCADE_NP_CONJ_FAST=0: conjunction searches through the general root isolation only (tests).
     bool np_conj_fast = std::getenv("CASCADE_NP_CONJ_FAST") == nullptr || std::atoi(std::getenv("CASCADE_NP_CONJ_FAST")) != 0;
     // per-kernel HIP-event timing (csc_profile_*)
@@ -312,6 +316,33 @@ __global__ __launch_bounds__(256) void k_conj_gather(uint32_t n, const uint4 *sr
         return;
     }
     dst[t] = src[static_cast<uint64_t>(idx[rec]) * 8u + (t & 7u)];
+}
+
+// Rows on demand: the objects that appear in a candidate list, and the rows they need.
+__global__ __launch_bounds__(256) void k_cand_mark(uint32_t ncand, const uint4 *cand, uint32_t *need)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncand) {
+        const uint4 c = cand[k];
+        need[c.x] = 1u;
+        need[c.y] = 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cand_weights(uint32_t n, const uint32_t *need, const uint32_t *nsub, uint32_t *w)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        w[i] = need[i] ? nsub[i] : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cand_compact(uint32_t n, const uint32_t *need, const uint64_t *off, uint32_t *list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && need[i]) {
+        list[off[i]] = i;
+    }
 }
 
 // Row compaction for the removal of particles: the row of particle i moves up by the number of
@@ -1455,7 +1486,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                        double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
                        const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
                        const double *d_tcs_vr, const double *d_tcoords, const np_source &src, uint64_t *n_coll,
-                       uint64_t *n_conj, uint32_t *warn_flags)
+                       uint64_t *n_conj, uint32_t *warn_flags, bool prefilter_only = false)
 {
     if (order != 20u) {
         ctx->err = "only Taylor order 20 is built";
@@ -1469,7 +1500,13 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
     if (warn_flags) {
         *warn_flags = 0;
     }
+    ctx->np_cand_valid = false;
     if (src.npairs == 0) {
+        if (prefilter_only) {
+            ctx->np_cand_list = nullptr;
+            ctx->np_cand_count = 0;
+            ctx->np_cand_valid = true;
+        }
         return CSC_OK;
     }
     if (src.npairs > 0xffffff00ull && src.cand == nullptr && src.srt_recs == nullptr) {
@@ -1566,6 +1603,21 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         } else {
             KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter<false>), dim3(src.norder * (csc::PB_SIZE / 64)), dim3(64), 0,
                                                      ctx->stream, q));
+        }
+        if (prefilter_only) {
+            // The candidates stay on the device for csc_narrow_phase_finish.
+            CSC_LAUNCH_CHECK();
+            CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            CSC_HIP(hipStreamSynchronize(ctx->stream));
+            if (h[5] <= cand_cap) {
+                ctx->np_candidates = h[5];
+                ctx->np_cand_list = q.cand;
+                ctx->np_cand_count = h[5];
+                ctx->np_cand_valid = true;
+                return CSC_OK;
+            }
+            cand_cap = std::max(cand_cap, h[5] + h[5] / 4u + 16u);
+            continue;
         }
         KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(cdiv(cand_cap, 64)), dim3(64), 0, ctx->stream, q));
         KT("k_np_fex_tr", hipLaunchKernelGGL((csc::k_np_fex_tr<20>), dim3(cdiv(defer_cap, 64)), dim3(64), 0, ctx->stream, q));
@@ -1737,6 +1789,90 @@ int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct
     np_source src;
     src.cand = d_rec;
     src.npairs = npairs;
+    return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
+                       d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, src, n_coll, n_conj, warn_flags);
+}
+
+int csc_narrow_phase_prefilter(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double conj_thresh, const float *d_srt_recs,
+                               uint64_t *n_cand)
+{
+    if (n != ctx->bp_n || nchunks > ctx->bp_chunks) {
+        return ctx->invalid("narrow phase does not match the last broad phase");
+    }
+    if (d_srt_recs == nullptr) {
+        return ctx->invalid("csc_narrow_phase_prefilter needs the sorted trajectory records");
+    }
+    np_source src;
+    if (ctx->bp_flat) {
+        src.flat_pairs = ctx->bp_flat_pairs;
+        src.flat_cap = ctx->bp_flat_cap;
+        src.flat_cnt = ctx->bp_flat_cnt;
+    }
+    src.order = ctx->bp_order;
+    src.norder = ctx->bp_blocks;
+    src.pb_count = ctx->bp_pl.pb_count;
+    src.pb_pairs = ctx->bp_pl.pairs;
+    src.vidx = ctx->bp_vidx;
+    src.srt_recs = d_srt_recs;
+    src.npairs = ctx->bp_total;
+    uint64_t nc = 0, nj = 0;
+    const int rc = narrow_impl(ctx, n, nchunks, 0., 0., 0., 0., conj_thresh, 20u, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, src, &nc, &nj, nullptr, true);
+    if (rc == CSC_OK && n_cand) {
+        *n_cand = ctx->np_cand_count;
+    }
+    return rc;
+}
+
+int csc_candidate_objects(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, uint32_t *d_list, uint32_t *n_list,
+                          uint64_t *n_rows)
+{
+    if (!ctx->np_cand_valid) {
+        return ctx->invalid("csc_candidate_objects needs a preceding csc_narrow_phase_prefilter");
+    }
+    *n_list = 0;
+    *n_rows = 0;
+    if (ctx->np_cand_count == 0 || n == 0) {
+        return CSC_OK;
+    }
+    const uint32_t nc = static_cast<uint32_t>(ctx->np_cand_count);
+    CSC_BUF(d_need, uint32_t, "cand_need", n);
+    CSC_BUF(d_w, uint32_t, "cand_weights", n);
+    CSC_BUF(d_off, uint64_t, "cand_off", n + 1ull);
+    CSC_BUF(d_roff, uint64_t, "cand_row_off", n + 1ull);
+    CSC_HIP(hipMemsetAsync(d_need, 0, n * sizeof(uint32_t), ctx->stream));
+    KT("k_cand_mark", hipLaunchKernelGGL(k_cand_mark, dim3(cdiv(nc, 256)), dim3(256), 0, ctx->stream, nc, ctx->np_cand_list, d_need));
+    KT("k_cand_weights", hipLaunchKernelGGL(k_cand_weights, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_need, d_nsub, d_w));
+    CSC_LAUNCH_CHECK();
+    if (const int rc = scan_impl(ctx, d_need, n, 1, d_off, nullptr)) {
+        return rc;
+    }
+    KT("k_cand_compact", hipLaunchKernelGGL(k_cand_compact, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_need, d_off, d_list));
+    CSC_LAUNCH_CHECK();
+    uint64_t tot[2] = {0, 0};
+    CSC_HIP(hipMemcpyAsync(&tot[0], d_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (const int rc = scan_impl(ctx, d_w, n, 1, d_roff, nullptr)) {
+        return rc;
+    }
+    CSC_HIP(hipMemcpyAsync(&tot[1], d_roff + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    *n_list = static_cast<uint32_t>(tot[0]);
+    *n_rows = tot[1];
+    return CSC_OK;
+}
+
+int csc_narrow_phase_finish(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                            double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                            const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub,
+                            const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords, uint64_t *n_coll,
+                            uint64_t *n_conj, uint32_t *warn_flags)
+{
+    if (!ctx->np_cand_valid) {
+        return ctx->invalid("csc_narrow_phase_finish needs a preceding csc_narrow_phase_prefilter");
+    }
+    np_source src;
+    src.cand = ctx->np_cand_list;
+    src.npairs = ctx->np_cand_count;
     return narrow_impl(ctx, n, nchunks, ct, delta_t, init_time_hi, init_time_lo, conj_thresh, order, d_state, d_active,
                        d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, src, n_coll, n_conj, warn_flags);
 }

@@ -378,6 +378,15 @@ struct sim::sim_data {
     // Inside propagate_until() nobody can touch the host vectors between the supersteps: the
     // state goes up once (loop_uploaded) and comes down once, when the loop ends.
     bool in_loop = false, loop_uploaded = false;
+    // Rows on demand (plain Kepler with the pre-filter): propagation writes no Taylor rows; after
+    // the pre-filter only the particles of the candidate pairs are integrated again to produce
+    // theirs (CASCADE_ROWS_ON_DEMAND=0 switches it off). sparse_likely: the candidates of the last
+    // superstep involved few particles; rows_full: every particle has its rows (what
+    // dense_propagate needs); want_full_rows: propagate_until announces the superstep whose rows
+    // it is going to evaluate.
+    bool rows_on_demand = std::getenv("CASCADE_ROWS_ON_DEMAND") == nullptr || std::atoi(std::getenv("CASCADE_ROWS_ON_DEMAND")) != 0;
+    bool sparse_likely = true, rows_full = true, want_full_rows = false, state_prestep = false;
+    csc_prop_cfg last_cfg{};
     // Dense-output rows in one pass: 0 never, 1 for everything but plain Kepler (default), 2 always
     // (environment CASCADE_SINGLE_PASS, for measurements); row_hint = most substeps of one particle
     // in the previous superstep (valid for the same ct and n_par_ct).
@@ -967,6 +976,21 @@ void sim::dense_propagate(double t)
 {
     auto &d = *m_data;
     const auto n = static_cast<std::uint32_t>(get_nparts());
+    if (!d.rows_full) {
+        // Rows on demand: only the particles of the candidate pairs have theirs. The state on the
+        // device is still the one the superstep started from (step() calls this before it
+        // advances the state; propagate_until announces the superstep it evaluates afterwards).
+        if (!d.state_prestep) {
+            throw std::logic_error("dense_propagate(): the Taylor rows of the last superstep are incomplete");
+        }
+        std::uint32_t xs = 0, vs = 0;
+        d.chk(csc_tc_strides(d.order, &xs, &vs));
+        const std::uint64_t tot = std::max<std::uint64_t>(d.stats.total_substeps, 1);
+        d.chk(csc_propagate_store(d.ctx, &d.last_cfg, n, d.get<double>("state"), d.get<std::uint32_t>("vidx"),
+                                  d.get<std::uint32_t>("nsub"), d.get<std::uint64_t>("tc_row"), d.buf<double>("tcs_xyz", tot * xs),
+                                  d.buf<double>("tcs_vr", tot * vs), d.buf<double>("tcoords", tot * 2u)));
+        d.rows_full = true;
+    }
     d.chk(csc_dense_propagate(d.ctx, n, d.order, t, d.get<std::uint64_t>("tc_row"), d.get<std::uint32_t>("nsub"),
                               d.get<double>("tcs_xyz"), d.get<double>("tcs_vr"), d.get<double>("tcoords"),
                               d.get<double>("final_state")));
@@ -977,6 +1001,7 @@ void sim::dense_propagate(double t)
     }
     d.chk(rc);
     d.chk(csc_copy_final_state(d.ctx, n, d.get<double>("final_state"), d.get<double>("state")));
+    d.state_prestep = false;
     if (d.host_sync && !d.in_loop) {
         download_state();
     }
@@ -1020,6 +1045,7 @@ outcome sim::step()
         d.loop_uploaded = true;
     }
 
+    d.state_prestep = true;
     const std::size_t cn = static_cast<std::size_t>(nchunks0) * n;
     double *d_state = d.buf<double>("state", n * 7ull);
     auto *d_active = d.buf<std::uint8_t>("active", n);
@@ -1107,8 +1133,11 @@ outcome sim::step()
     if (d.row_hint_ct != m_ct || d.row_hint_nchunks != nchunks0) {
         d.row_hint = 0;
     }
+    const bool sparse = d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && d.sparse_likely
+                        && !d.want_full_rows;
     std::uint32_t row_cap = 0;
-    if (d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler) && d.row_hint != 0u) {
+    if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler)
+        && d.row_hint != 0u) {
         row_cap = d.row_hint + std::max(2u, d.row_hint / 4u);
         if (static_cast<double>(n) * row_cap * (xs + vs + 2u) * 8. > 96e9) {
             row_cap = 0; // would not fit comfortably: two passes
@@ -1167,14 +1196,8 @@ outcome sim::step()
     d.chk(csc_morton_encode(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes));
     d.chk(csc_sort_gather(ctx, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs));
 
-    // Taylor coefficients for dense output, two-pass mode: CSR rows in the Morton order of chunk 0.
     const std::uint64_t tot = summ.total_substeps;
-    if (!rows_done) {
-        d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(tot, 1) * xs);
-        d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(tot, 1) * vs);
-        d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
-        d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
-    }
+    d.last_cfg = cfg;
     d.chk(csc_bvh_build(ctx, n, nchunks, d_scodes, d_slbs, d_subs));
     std::uint64_t npairs = 0;
     d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));
@@ -1189,8 +1212,45 @@ outcome sim::step()
     pt.lap("sort/bvh/bp");
     std::uint64_t ncoll = 0, nconj = 0;
     std::uint32_t warn = 0;
-    d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
-                           d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
+    // Taylor coefficients for dense output when the integration did not write them: exact-fit CSR
+    // rows, of every particle in the Morton order of chunk 0 (two-pass mode), or only of the
+    // particles that the candidate pairs involve.
+    auto store_all = [&]() {
+        d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(tot, 1) * xs);
+        d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(tot, 1) * vs);
+        d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
+        d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
+        d.rows_full = true;
+    };
+    if (sparse) {
+        std::uint64_t ncand = 0, nrows = 0;
+        std::uint32_t nlist = 0;
+        d.chk(csc_narrow_phase_prefilter(ctx, n, nchunks, m_conj_thresh, d_srecs, &ncand));
+        auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
+        d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, &nrows));
+        if (static_cast<std::uint64_t>(nlist) * 4u > n) {
+            store_all();
+        } else {
+            d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(nrows, 1) * xs);
+            d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(nrows, 1) * vs);
+            d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(nrows, 1) * 2u);
+            if (nlist) {
+                d.chk(csc_propagate_store(ctx, &cfg, nlist, d_state, d_list, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
+            }
+            d.rows_full = false;
+        }
+        d.chk(csc_narrow_phase_finish(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state,
+                                      d_active, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, &ncoll, &nconj, &warn));
+    } else {
+        if (!rows_done) {
+            store_all();
+        } else {
+            d.rows_full = true;
+        }
+        d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
+                               d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
+    }
+    d.sparse_likely = csc_narrow_phase_candidates(ctx) * 8u <= n;
     // The event lists stay in the context (pinned host memory; a conjunction-heavy superstep
     // yields millions of 128-byte records): no copies besides the append to m_det_conj below.
     const csc_collision *coll_p = nullptr;
@@ -1251,6 +1311,7 @@ outcome sim::step()
     if (oc == outcome::success) {
         d.time = df_add(d.time, dfloat{delta_t0, 0.});
         d.chk(csc_copy_final_state(ctx, n, d_final, d_state));
+        d.state_prestep = false;
         if (d.host_sync && !d.in_loop) {
             download_state();
         }
@@ -1312,6 +1373,16 @@ outcome sim::propagate_until(double t)
     d.loop_uploaded = false;
     while (true) {
         const dfloat orig_t = d.time;
+        // The superstep that reaches the final time is evaluated by dense_propagate() below: it
+        // keeps the rows of every particle (the time a successful step() arrives at is known).
+        d.want_full_rows = !df_lt(df_add(d.time, dfloat{m_ct * m_n_par_ct, 0.}), final_t);
+        struct reset_flag {
+            bool &f;
+            ~reset_flag()
+            {
+                f = false;
+            }
+        } rf{d.want_full_rows};
         const outcome cur = step();
         if (cur == outcome::success) {
             if (!df_lt(d.time, final_t)) {

@@ -313,6 +313,24 @@ int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, doub
                      const double *d_tcs_vr, const double *d_tcoords, const float *d_srt_recs, uint64_t *n_coll,
                      uint64_t *n_conj, uint32_t *warn_flags);
 uint64_t csc_narrow_phase_candidates(csc_ctx *ctx);
+/* The same narrow phase in two calls, for callers that produce the Taylor rows on demand: the
+ * reference stores the rows of every particle (the propagate callback, src/sim_propagate.cpp:710-755)
+ * although narrow_phase_parallel (src/sim_narrow_phase.cpp:495-1023) reads only those of the pairs
+ * it tests, and the pre-filter leaves ~0.1 % of the pairs. csc_narrow_phase_prefilter runs the
+ * pre-filter over the pairs of the last broad phase and keeps the candidates on the device;
+ * csc_candidate_objects lists the particles they involve (d_list [n] receives n_list ascending
+ * indices; n_rows = the sum of their substep counts), so that csc_propagate_store on that list
+ * writes just their rows; csc_narrow_phase_finish then runs the polynomial tests on the
+ * candidates. Same events as csc_narrow_phase. */
+int csc_narrow_phase_prefilter(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double conj_thresh, const float *d_srt_recs,
+                               uint64_t *n_cand);
+int csc_candidate_objects(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, uint32_t *d_list, uint32_t *n_list,
+                          uint64_t *n_rows);
+int csc_narrow_phase_finish(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
+                            double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
+                            const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub,
+                            const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords, uint64_t *n_coll,
+                            uint64_t *n_conj, uint32_t *warn_flags);
 /* Same, on a caller-provided pair list d_pairs [npairs][2] with per-chunk row offsets
  * pair_off [nchunks + 1] (host array). For parity checks on injected pairs. */
 int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,

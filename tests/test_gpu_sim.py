@@ -401,3 +401,37 @@ def test_conj_register_search_same_bits(n_par_ct, monkeypatch):
         out.append(np.array(s.conjunctions))
     assert len(out[0]) > 1000
     assert out[0].tobytes() == out[1].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_par_ct,conj", [(1, 0.0), (3, 2e-3)])
+def test_rows_on_demand_change_nothing(n_par_ct, conj, monkeypatch):
+    """Plain Kepler writes no Taylor rows while it integrates: the particles of the candidate pairs
+    are integrated again after the pre-filter (csc_narrow_phase_prefilter / csc_candidate_objects /
+    csc_propagate_store on the list / csc_narrow_phase_finish), every particle only when
+    dense_propagate needs them (interrupts, the last superstep of propagate_until). Against the
+    rows written during the integration (CASCADE_ROWS_ON_DEMAND=0): same outcomes, states,
+    conjunctions, bit for bit."""
+    from cascade_amd import outcome, sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(20000, 5)
+    st[:, 6] *= 5e3  # collisions within a few supersteps
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CASCADE_ROWS_ON_DEMAND", mode)
+        s = sim(st, 0.23, n_par_ct=n_par_ct, conj_thresh=conj)
+        log = []
+        for _ in range(6):
+            oc = s.step()
+            info = s.interrupt_info
+            log.append((oc, tuple(info) if isinstance(info, list) else info, s.time))
+            if oc == outcome.collision:
+                s.remove_particles(list(info))
+        oc = s.propagate_until(s.time + 0.23 * n_par_ct * 2.4)
+        log.append((oc, s.time))
+        res.append((log, np.array(s.state), np.array(s.conjunctions)))
+    assert any(oc == outcome.collision for oc, *_ in res[0][0][:-1])
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][2].tobytes() == res[1][2].tobytes()
