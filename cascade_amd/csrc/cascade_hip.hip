@@ -1831,18 +1831,17 @@ int csc_candidate_objects(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, uint
         return ctx->invalid("csc_candidate_objects needs a preceding csc_narrow_phase_prefilter");
     }
     *n_list = 0;
-    *n_rows = 0;
+    if (n_rows) {
+        *n_rows = 0;
+    }
     if (ctx->np_cand_count == 0 || n == 0) {
         return CSC_OK;
     }
     const uint32_t nc = static_cast<uint32_t>(ctx->np_cand_count);
     CSC_BUF(d_need, uint32_t, "cand_need", n);
-    CSC_BUF(d_w, uint32_t, "cand_weights", n);
     CSC_BUF(d_off, uint64_t, "cand_off", n + 1ull);
-    CSC_BUF(d_roff, uint64_t, "cand_row_off", n + 1ull);
     CSC_HIP(hipMemsetAsync(d_need, 0, n * sizeof(uint32_t), ctx->stream));
     KT("k_cand_mark", hipLaunchKernelGGL(k_cand_mark, dim3(cdiv(nc, 256)), dim3(256), 0, ctx->stream, nc, ctx->np_cand_list, d_need));
-    KT("k_cand_weights", hipLaunchKernelGGL(k_cand_weights, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_need, d_nsub, d_w));
     CSC_LAUNCH_CHECK();
     if (const int rc = scan_impl(ctx, d_need, n, 1, d_off, nullptr)) {
         return rc;
@@ -1851,13 +1850,21 @@ int csc_candidate_objects(csc_ctx *ctx, uint32_t n, const uint32_t *d_nsub, uint
     CSC_LAUNCH_CHECK();
     uint64_t tot[2] = {0, 0};
     CSC_HIP(hipMemcpyAsync(&tot[0], d_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (const int rc = scan_impl(ctx, d_w, n, 1, d_roff, nullptr)) {
-        return rc;
+    if (n_rows) {
+        CSC_BUF(d_w, uint32_t, "cand_weights", n);
+        CSC_BUF(d_roff, uint64_t, "cand_row_off", n + 1ull);
+        KT("k_cand_weights", hipLaunchKernelGGL(k_cand_weights, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, d_need, d_nsub, d_w));
+        CSC_LAUNCH_CHECK();
+        if (const int rc = scan_impl(ctx, d_w, n, 1, d_roff, nullptr)) {
+            return rc;
+        }
+        CSC_HIP(hipMemcpyAsync(&tot[1], d_roff + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    CSC_HIP(hipMemcpyAsync(&tot[1], d_roff + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CSC_HIP(hipStreamSynchronize(ctx->stream));
     *n_list = static_cast<uint32_t>(tot[0]);
-    *n_rows = tot[1];
+    if (n_rows) {
+        *n_rows = tot[1];
+    }
     return CSC_OK;
 }
 

@@ -1227,7 +1227,8 @@ outcome sim::step()
         std::uint32_t nlist = 0;
         d.chk(csc_narrow_phase_prefilter(ctx, n, nchunks, m_conj_thresh, d_srecs, &ncand));
         auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
-        d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, &nrows));
+        d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, nullptr));
+        nrows = static_cast<std::uint64_t>(nlist) * summ.max_substeps; // (an upper bound is enough)
         if (static_cast<std::uint64_t>(nlist) * 4u > n) {
             store_all();
         } else {

@@ -319,7 +319,7 @@ uint64_t csc_narrow_phase_candidates(csc_ctx *ctx);
  * it tests, and the pre-filter leaves ~0.1 % of the pairs. csc_narrow_phase_prefilter runs the
  * pre-filter over the pairs of the last broad phase and keeps the candidates on the device;
  * csc_candidate_objects lists the particles they involve (d_list [n] receives n_list ascending
- * indices; n_rows = the sum of their substep counts), so that csc_propagate_store on that list
+ * indices; n_rows, when not NULL, the sum of their substep counts), so that csc_propagate_store on that list
  * writes just their rows; csc_narrow_phase_finish then runs the polynomial tests on the
  * candidates. Same events as csc_narrow_phase. */
 int csc_narrow_phase_prefilter(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double conj_thresh, const float *d_srt_recs,
