@@ -318,6 +318,77 @@ __global__ __launch_bounds__(256) void k_conj_gather(uint32_t n, const uint4 *sr
     dst[t] = src[static_cast<uint64_t>(idx[rec]) * 8u + (t & 7u)];
 }
 
+// Propagation sharded over GPUs: everything pass 1 leaves per particle, as ONE record of
+// 80 + 96 C bytes, so that one all-gather moves it: {nsub, status, ev_idx, pad, ev_time, nf_last_t,
+// final_state[6]} then per chunk {lb, ub, trajectory record[4]} (float4 each).
+struct shard_arrays {
+    uint32_t *nsub;
+    int32_t *status;
+    uint32_t *ev_idx;
+    double *ev_time, *nf_last_t, *final_state;
+    float4 *lbs, *ubs, *recs; // recs may be null
+};
+
+__host__ __device__ inline size_t shard_record_bytes(uint32_t nchunks)
+{
+    return 80u + 96u * static_cast<size_t>(nchunks);
+}
+
+// UNPACK = false: particle first + k -> record k of buf; true: record k of buf -> particle
+// (k / per_rank) * per_rank + k % per_rank = k, for the records that hold a particle (k < n).
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void k_shard_records(uint32_t first, uint32_t count, uint32_t n, uint32_t nchunks, shard_arrays a,
+                                                       unsigned char *buf)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) {
+        return;
+    }
+    const uint32_t i = first + k;
+    unsigned char *rec = buf + static_cast<size_t>(k) * shard_record_bytes(nchunks);
+    uint32_t *r32 = reinterpret_cast<uint32_t *>(rec);
+    double *r64 = reinterpret_cast<double *>(rec);
+    float4 *rf4 = reinterpret_cast<float4 *>(rec + 80);
+    if constexpr (!UNPACK) {
+        r32[0] = a.nsub[i];
+        r32[1] = static_cast<uint32_t>(a.status[i]);
+        r32[2] = a.ev_idx[i];
+        r32[3] = 0u;
+        r64[2] = a.ev_time[i];
+        r64[3] = a.nf_last_t[i];
+        for (int j = 0; j < 6; ++j) {
+            r64[4 + j] = a.final_state[static_cast<size_t>(i) * 6u + j];
+        }
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const size_t e = static_cast<size_t>(c) * n + i;
+            rf4[c * 6u] = a.lbs[e];
+            rf4[c * 6u + 1u] = a.ubs[e];
+            for (int j = 0; j < 4; ++j) {
+                rf4[c * 6u + 2u + j] = a.recs ? a.recs[e * 4u + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    } else {
+        a.nsub[i] = r32[0];
+        a.status[i] = static_cast<int32_t>(r32[1]);
+        a.ev_idx[i] = r32[2];
+        a.ev_time[i] = r64[2];
+        a.nf_last_t[i] = r64[3];
+        for (int j = 0; j < 6; ++j) {
+            a.final_state[static_cast<size_t>(i) * 6u + j] = r64[4 + j];
+        }
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const size_t e = static_cast<size_t>(c) * n + i;
+            a.lbs[e] = rf4[c * 6u];
+            a.ubs[e] = rf4[c * 6u + 1u];
+            if (a.recs) {
+                for (int j = 0; j < 4; ++j) {
+                    a.recs[e * 4u + j] = rf4[c * 6u + 2u + j];
+                }
+            }
+        }
+    }
+}
+
 // Rows on demand: the objects that appear in a candidate list, and the rows they need.
 __global__ __launch_bounds__(256) void k_cand_mark(uint32_t ncand, const uint4 *cand, uint32_t *need)
 {
@@ -426,6 +497,8 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
     csc::prop_params p{};
     p.state = d_state;
     p.n = n;
+    p.first = 0;
+    p.n_total = n;
     p.init_hi = cfg->init_time_hi;
     p.init_lo = cfg->init_time_lo;
     p.delta_t = cfg->delta_t;
@@ -761,7 +834,8 @@ int csc_check_flags(csc_ctx *ctx)
 static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                           int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
                           double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,
-                          uint64_t *d_tc_row, double *d_tcs_xyz, double *d_tcs_vr, double *d_tcoords)
+                          uint64_t *d_tc_row, double *d_tcs_xyz, double *d_tcs_vr, double *d_tcoords, uint32_t first = 0,
+                          uint32_t count = 0xffffffffu)
 {
     if (const int rc = check_cfg(ctx, cfg)) {
         return rc;
@@ -769,7 +843,19 @@ static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, con
     if (n == 0u) {
         return ctx->invalid("Cannot integrate a simulation with no particles");
     }
+    const uint32_t n_total = n;
+    if (count != 0xffffffffu) {
+        if (first > n_total || count > n_total - first) {
+            return ctx->invalid("csc_propagate_range: the range does not lie within the particles");
+        }
+        if (count == 0u) {
+            return CSC_OK;
+        }
+        n = count;
+    }
     csc::prop_params p = make_prop_params(cfg, n, d_state);
+    p.first = count != 0xffffffffu ? first : 0u;
+    p.n_total = n_total;
     p.nsub = d_nsub;
     p.status = d_status;
     p.ev_idx = d_ev_idx;
@@ -802,6 +888,54 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
 {
     return propagate_impl(ctx, cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, d_lbs,
                           d_ubs, d_recs, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+size_t csc_shard_record_bytes(uint32_t nchunks)
+{
+    return shard_record_bytes(nchunks);
+}
+
+int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t nchunks, const uint32_t *d_nsub,
+                   const int32_t *d_status, const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,
+                   const double *d_final_state, const float *d_lbs, const float *d_ubs, const float *d_recs, void *d_records)
+{
+    if (first > n || count > n - first) {
+        return ctx->invalid("csc_shard_pack: the range does not lie within the particles");
+    }
+    if (count == 0u) {
+        return CSC_OK;
+    }
+    shard_arrays a{const_cast<uint32_t *>(d_nsub), const_cast<int32_t *>(d_status), const_cast<uint32_t *>(d_ev_idx),
+                   const_cast<double *>(d_ev_time), const_cast<double *>(d_nf_last_t), const_cast<double *>(d_final_state),
+                   reinterpret_cast<float4 *>(const_cast<float *>(d_lbs)), reinterpret_cast<float4 *>(const_cast<float *>(d_ubs)),
+                   reinterpret_cast<float4 *>(const_cast<float *>(d_recs))};
+    KT("k_shard_pack", hipLaunchKernelGGL((k_shard_records<false>), dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, first, count, n,
+                                           nchunks, a, static_cast<unsigned char *>(d_records)));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const void *d_records, uint32_t *d_nsub, int32_t *d_status,
+                     uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t, double *d_final_state, float *d_lbs,
+                     float *d_ubs, float *d_recs)
+{
+    if (n == 0u) {
+        return CSC_OK;
+    }
+    shard_arrays a{d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, reinterpret_cast<float4 *>(d_lbs),
+                   reinterpret_cast<float4 *>(d_ubs), reinterpret_cast<float4 *>(d_recs)};
+    KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, 0u, n, n, nchunks, a,
+                                             static_cast<unsigned char *>(const_cast<void *>(d_records))));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_propagate_range(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
+                        const double *d_state, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
+                        double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs)
+{
+    return propagate_impl(ctx, cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, d_lbs,
+                          d_ubs, d_recs, 0, nullptr, nullptr, nullptr, nullptr, first, count);
 }
 
 int csc_propagate_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,

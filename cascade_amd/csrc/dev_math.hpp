@@ -659,7 +659,7 @@ struct rf_path {
 constexpr int RF_MAX_ORDER = 20;
 
 // poly: order+1 coefficients (NOT rescaled). direction: -1, 0, +1.
-__device__ inline int isolate_and_refine(const double *poly, int order, double rf_int, int direction, double *roots,
+__device__ __forceinline__ int isolate_and_refine(const double *poly, int order, double rf_int, int direction, double *roots,
                                          int max_roots, int *warn)
 {
     double root_poly[RF_MAX_ORDER + 1]; // poly rescaled to [0, 1)

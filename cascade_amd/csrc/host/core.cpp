@@ -335,10 +335,25 @@ PYBIND11_MODULE(core, m)
                 s.set_shard(rank, nranks, std::move(fn));
             },
             "rank"_a, "nranks"_a, "exchange"_a = py::none{})
+        .def(
+            "set_shard_propagation",
+            [](sim &s, py::object gather) {
+                // gather(send_address, recv_address, nbytes): all-gather of device memory.
+                sim::gather_t fn;
+                if (!gather.is_none()) {
+                    fn = [gather](std::uintptr_t send, std::uintptr_t recv, std::size_t bytes) {
+                        py::gil_scoped_acquire gil;
+                        gather(send, recv, bytes);
+                    };
+                }
+                s.set_shard_propagation(std::move(fn));
+            },
+            "gather"_a = py::none{})
         .def("upload_state", &sim::upload_state)
         .def("download_state", &sim::download_state)
         .def_property_readonly("last_bp_pairs", [](const sim &s) { return s.get_step_stats().bp_pairs; })
         .def_property_readonly("last_np_candidates", [](const sim &s) { return s.get_step_stats().np_candidates; })
+        .def_property_readonly("last_propagated", [](const sim &s) { return s.get_step_stats().propagated; })
         .def_property_readonly("last_bp_node_pairs", [](const sim &s) { return s.get_step_stats().bp_node_pairs; })
         .def_property_readonly("last_total_substeps", [](const sim &s) { return s.get_step_stats().total_substeps; })
         .def_property_readonly("last_nchunks", [](const sim &s) { return s.get_step_stats().nchunks; })

@@ -395,6 +395,7 @@ struct sim::sim_data {
     double row_hint_ct = 0;
     std::uint32_t shard_rank = 0, shard_n = 1;
     exchange_t exchange;
+    gather_t gather; // propagation sharded too when set
     step_stats stats;
     std::vector<std::tuple<size_type, size_type, double>> last_coll;
     std::vector<conjunction> last_conj;
@@ -414,7 +415,7 @@ struct sim::sim_data {
         : dyn(o.dyn), tape(o.tape), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
           single_pass_mode(o.single_pass_mode),
-          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange)
+          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather)
     {
     }
     ~sim_data()
@@ -866,6 +867,11 @@ void sim::set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchang
     m_data->exchange = std::move(exchange);
 }
 
+void sim::set_shard_propagation(gather_t gather)
+{
+    m_data->gather = std::move(gather);
+}
+
 void sim::set_np_prefilter(bool v)
 {
     m_data->np_prefilter = v;
@@ -1133,8 +1139,12 @@ outcome sim::step()
     if (d.row_hint_ct != m_ct || d.row_hint_nchunks != nchunks0) {
         d.row_hint = 0;
     }
-    const bool sparse = d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && d.sparse_likely
-                        && !d.want_full_rows;
+    // Propagation sharded over the processes: pass 1 without rows on this process's range, then
+    // one all-gather; the rows are produced on demand whatever the dynamics.
+    const bool shard_prop = d.shard_n > 1u && static_cast<bool>(d.gather) && d.np_prefilter;
+    const bool sparse = shard_prop
+                        || (d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && d.sparse_likely
+                            && !d.want_full_rows);
     std::uint32_t row_cap = 0;
     if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler)
         && d.row_hint != 0u) {
@@ -1151,8 +1161,27 @@ outcome sim::step()
         d_tco = d.buf<double>("tcoords", rows * 2u);
         d.chk(csc_propagate_rows(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
                                  d_recs, row_cap, d_tc_row, d_txyz, d_tvr, d_tco));
+    } else if (shard_prop) {
+        const std::uint32_t per = (n + d.shard_n - 1u) / d.shard_n;
+        const std::uint32_t first = std::min(n, d.shard_rank * per), count = std::min(per, n - first);
+        const std::size_t rec = csc_shard_record_bytes(nchunks0);
+        auto *d_send = d.buf<unsigned char>("shard_send", static_cast<std::size_t>(per) * rec);
+        auto *d_recv = d.buf<unsigned char>("shard_recv", static_cast<std::size_t>(per) * d.shard_n * rec);
+        d.chk(csc_propagate_range(ctx, &cfg, n, first, count, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final,
+                                  d_lbs, d_ubs, d_recs));
+        d.chk(csc_shard_pack(ctx, n, first, count, nchunks0, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
+                             d_recs, d_send));
+        d.chk(csc_sync(ctx));
+        d.gather(reinterpret_cast<std::uintptr_t>(d_send), reinterpret_cast<std::uintptr_t>(d_recv),
+                 static_cast<std::size_t>(per) * rec);
+        d.stats.propagated = count;
+        d.chk(csc_shard_unpack(ctx, n, nchunks0, d_recv, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
+                               d_recs));
     } else {
         d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
+    }
+    if (!shard_prop) {
+        d.stats.propagated = n;
     }
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
@@ -1229,7 +1258,7 @@ outcome sim::step()
         auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
         d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, nullptr));
         nrows = static_cast<std::uint64_t>(nlist) * summ.max_substeps; // (an upper bound is enough)
-        if (static_cast<std::uint64_t>(nlist) * 4u > n) {
+        if (static_cast<std::uint64_t>(nlist) * 4u > n || d.want_full_rows) {
             store_all();
         } else {
             d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(nrows, 1) * xs);

@@ -106,6 +106,9 @@ struct prop_params {
     // integration into the fixed slots [i * row_cap, (i + 1) * row_cap) of particle i
     // (tcs_xyz / tcs_vr / tcoords / tc_row below), and there is no second pass.
     std::uint32_t row_cap;
+    // Pass 1 over a range of particles (propagation sharded over GPUs): lane k handles particle
+    // first + k, k < n, and the per-chunk arrays hold n_total particles per chunk.
+    std::uint32_t first, n_total;
     // pass 2
     const std::uint32_t *order;     // [N] particle handled by lane k (null = identity)
     const std::uint64_t *row_base;  // [N] first CSR row of lane k
@@ -625,15 +628,19 @@ CSC_DEV bool descartes_no_root(const double *g, double h)
 // Slow path of terminal-event detection: full root isolation on g over [0, h).
 // Returns the earliest accepted root or a negative value if there is none.
 template <int P>
-CSC_DEV_NOINLINE double event_first_root(const double *g_in, double h, int direction, int *warn)
+CSC_DEV double event_first_root(const double *g_in, double h, int direction, int *warn)
 {
+    // (The runtime-order search on purpose: this out-of-line call sits in the middle of the
+    // integration loop with every Taylor series live in registers, and the register-resident
+    // isolate_and_refine_n needs so many registers that the compiler spills SGPRs into VGPR lanes
+    // inside the callee -- lanes of the callers' registers that belong to particles which are
+    // not taking part in the call. Seen as a substep counter reset in a neighbouring lane.)
     double g[P + 1];
-#pragma unroll
     for (int i = 0; i <= P; ++i) {
         g[i] = g_in[i];
     }
     double roots[P + 1];
-    int n = isolate_and_refine_n<P>(g, h, direction, roots, P + 1, warn);
+    int n = isolate_and_refine(g, P, h, direction, roots, P + 1, warn);
     if (n < 0) {
         n = -1 - n;
     }
@@ -652,7 +659,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
     if (lane_k >= prm.n) {
         return;
     }
-    std::uint32_t i = lane_k;
+    std::uint32_t i = prm.first + lane_k;
     if constexpr (STORE) {
         if (prm.order != nullptr) {
             i = prm.order[lane_k];
@@ -705,7 +712,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
         if (want_recs) {
             // Chunks that are never completed keep an invalid record (dev = +inf: never excluded).
             for (std::uint32_t k = 0; k < C; ++k) {
-                float4 *pr = reinterpret_cast<float4 *>(prm.recs) + (static_cast<std::size_t>(k) * prm.n + i) * 4u;
+                float4 *pr = reinterpret_cast<float4 *>(prm.recs) + (static_cast<std::size_t>(k) * prm.n_total + i) * 4u;
                 pr[3] = make_float4(0.f, 0.f, 0.f, finf);
             }
         }
@@ -713,8 +720,8 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
     if constexpr (!STORE) {
         // Boxes of chunks that no substep reaches stay at +-inf (:238-244).
         for (std::uint32_t k = 0; k < C; ++k) {
-            float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(k) * prm.n + i);
-            float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(k) * prm.n + i);
+            float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(k) * prm.n_total + i);
+            float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(k) * prm.n_total + i);
             *plo = make_float4(finf, finf, finf, finf);
             *phi = make_float4(-finf, -finf, -finf, -finf);
         }
@@ -722,8 +729,8 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
     auto flush_box = [&]() {
         if constexpr (!STORE) {
             if (kbox != ~0u) {
-                float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(kbox) * prm.n + i);
-                float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(kbox) * prm.n + i);
+                float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(kbox) * prm.n_total + i);
+                float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(kbox) * prm.n_total + i);
                 *plo = make_float4(blo[0], blo[1], blo[2], blo[3]);
                 *phi = make_float4(bhi[0], bhi[1], bhi[2], bhi[3]);
                 if (want_recs) {
@@ -735,7 +742,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                     // arithmetic of the filter.
                     double dev = sbound * dts * dts * 0.125 + p_radius + 1e-6 * sabs;
                     float devf = (smask == 0x1fu && finite_d(dev)) ? nextafterf(static_cast<float>(dev), finf) : finf;
-                    float4 *pr = reinterpret_cast<float4 *>(prm.recs) + (static_cast<std::size_t>(kbox) * prm.n + i) * 4u;
+                    float4 *pr = reinterpret_cast<float4 *>(prm.recs) + (static_cast<std::size_t>(kbox) * prm.n_total + i) * 4u;
                     pr[0] = make_float4(smp[0], smp[1], smp[2], smp[3]);
                     pr[1] = make_float4(smp[4], smp[5], smp[6], smp[7]);
                     pr[2] = make_float4(smp[8], smp[9], smp[10], smp[11]);

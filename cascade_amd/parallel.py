@@ -58,12 +58,47 @@ def make_event_exchange(group=None, device=None):
     return exchange
 
 
-def shard(sim_obj, group=None):
+class _DeviceBytes:
+    """A stretch of device memory owned by the simulation, as torch sees it."""
+
+    def __init__(self, address, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(address), False), "version": 2}
+
+
+def make_device_gather(group=None):
+    """gather(send_address, recv_address, nbytes): all-gather of ``nbytes`` bytes of device memory
+    per process (what ``sim.set_shard_propagation`` expects). RCCL moves the buffers in place;
+    with the gloo backend (the CPU tests) they are staged through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    on_device = dist.get_backend(group) == "nccl"
+
+    def gather(send_address, recv_address, nbytes):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        send = torch.as_tensor(_DeviceBytes(send_address, nbytes), device=dev)
+        recv = torch.as_tensor(_DeviceBytes(recv_address, nbytes * world), device=dev)
+        if on_device:
+            dist.all_gather_into_tensor(recv, send, group=group)
+        else:
+            out = torch.empty(nbytes * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, send.cpu(), group=group)
+            recv.copy_(out)
+        torch.cuda.synchronize(dev)
+
+    return gather
+
+
+def shard(sim_obj, group=None, propagation=False):
     """Shard ``sim_obj`` over the processes of ``group`` (call it on every process, on
-    simulations constructed from the same arguments)."""
+    simulations constructed from the same arguments). ``propagation=True`` shards the
+    integration too (one all-gather of 80 + 96 C bytes per particle and superstep): worth it when
+    the integration dominates the superstep, see DESIGN.md section 7."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if world > 1:
         sim_obj.set_shard(rank, world, make_event_exchange(group))
+        sim_obj.set_shard_propagation(make_device_gather(group) if propagation else None)
     return sim_obj

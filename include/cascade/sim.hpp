@@ -208,6 +208,7 @@ public:
     struct step_stats {
         std::uint64_t bp_pairs = 0;       // AABB pairs found by the broad phase
         std::uint64_t bp_node_pairs = 0;  // node pairs expanded by the broad phase's dual traversal
+        std::uint64_t propagated = 0;     // particles this process integrated in the first pass
         std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles
         std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)
@@ -383,6 +384,16 @@ public:
     using collision_t = std::tuple<size_type, size_type, double>;
     using exchange_t = std::function<void(std::vector<collision_t> &, std::vector<conjunction> &)>;
     void set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchange);
+    // Propagation sharded too (the north star's exchange: every process integrates the particles
+    // [rank * m, (rank + 1) * m), m = ceil(N / nranks), and the per-particle results -- substep
+    // counts, events, final states, per-chunk boxes and trajectory records, 80 + 96 C bytes each --
+    // are all-gathered; Taylor rows are produced on demand where the narrow phase needs them).
+    // `gather(send, recv, bytes)` must all-gather `bytes` bytes from the device address `send` of
+    // every process into the device address `recv` (rank-major) and return when the data is
+    // there. Pays when the integration dominates the superstep (expensive right-hand sides,
+    // many chunks); for 1M Kepler objects the replicated integration is cheaper than the gather.
+    using gather_t = std::function<void(std::uintptr_t, std::uintptr_t, std::size_t)>;
+    void set_shard_propagation(gather_t gather);
     // Geometric pre-filter in front of the polynomial narrow phase (on by default; it never
     // changes the detected events, see k_np_prefilter).
     void set_np_prefilter(bool);

@@ -347,6 +347,28 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
 int csc_narrow_phase_view(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, const csc_conjunction **conj,
                           uint64_t *n_conj);
 
+/* ---- propagation sharded over GPUs ("particles are sharded for propagation, chunk
+ * AABBs and Morton codes are gathered with RCCL all-gather") -------------------------------
+ * No counterpart in the reference, which is single-process. csc_propagate_range is csc_propagate
+ * for the particles [first, first + count) only (the arrays keep their full size n). What it
+ * leaves per particle -- substep count, status, event, final state, the per-chunk boxes and
+ * trajectory records -- is packed into one record of csc_shard_record_bytes(nchunks) bytes
+ * (csc_shard_pack: particle first + k -> record k), so that ONE all-gather of equal-sized blocks
+ * (per_rank = ceil(n / nranks) records from every process, rank r owning the particles from
+ * r * per_rank) moves it; csc_shard_unpack scatters the gathered records (record i = particle i)
+ * back into the arrays. The Taylor rows do not travel: they are produced on demand
+ * (csc_narrow_phase_prefilter ... csc_narrow_phase_finish). Asynchronous. */
+int csc_propagate_range(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
+                        const double *d_state, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
+                        double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs);
+size_t csc_shard_record_bytes(uint32_t nchunks);
+int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t nchunks, const uint32_t *d_nsub,
+                   const int32_t *d_status, const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,
+                   const double *d_final_state, const float *d_lbs, const float *d_ubs, const float *d_recs, void *d_records);
+int csc_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const void *d_records, uint32_t *d_nsub, int32_t *d_status,
+                     uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t, double *d_final_state, float *d_lbs,
+                     float *d_ubs, float *d_recs);
+
 /* ---- K8: dense output ------------------------------------------------------------------
  * dense_propagate (src/sim_propagate.cpp:1386-1503): state of every particle at time t
  * (relative to the superstep start) into d_out [n][6]. Asynchronous; a particle without

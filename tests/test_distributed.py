@@ -47,3 +47,11 @@ def test_sharded_sim_matches_unsharded():
     outcomes, interrupt info, states and conjunction lists as the unsharded simulation; the
     shards' pair counts add up to the full count."""
     _run_world("sim")
+
+
+@pytest.mark.gpu
+def test_sharded_propagation_matches_unsharded():
+    """Three processes, each integrating its own range of particles (all on cuda:0, gloo staging
+    of the all-gather): same outcomes, states, event lists as the unsharded simulation, for plain
+    Kepler with collisions / conjunctions and for J2 + drag with reentries and removals."""
+    _run_world("simprop", world=3)
