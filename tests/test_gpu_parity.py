@@ -314,3 +314,21 @@ def test_dense_output(orc, ctx):
     assert s.propagate_until(0.5) == "time_limit"
     chk(L.csc_dense_propagate(h, 500, 20, 0.5, g["dev"]["row"].ptr, g["dev"]["nsub"].ptr, g["dev"]["xyz"].ptr, g["dev"]["vr"].ptr, g["dev"]["tco"].ptr, d_out.ptr))
     assert _rel_close(d_out.download(), s.state[:, :6])
+
+
+@pytest.mark.parametrize("order", [None, [2, 0, 1]])
+def test_store_pass_next_to_terminal_events(orc, ctx, order):
+    """Particles of one wave that take the terminal-event root search at different substeps (one
+    leaves the domain in its first substep, one re-enters in its fourth, one meets no event): the
+    store pass writes the same substeps as the first pass counted, and they are the oracle's.
+    (The root search used to be an out-of-line call inside the integration loop; it reset the
+    substep counter of the lane that was not part of the call.)"""
+    orc.lib().orc_rhofac.restype = C.c_double
+    orc.lib().orc_rhofac.argtypes = [C.c_uint32]
+    st = np.array([[0.99, 0, 0, 1, 0, 0, 1e-6], [1.01, 0, 0, -1, 0, 0, 1e-6], [4.9, 0, 0, 1, 0, 0, 1e-6]])
+    s = orc.Sim(st, 0.23, n_par_ct=3, exit_radius=5.0, reentry_radius=0.75)
+    s.step()
+    nsub, tcs, tco = s.substeps()
+    g = _gpu_propagate(ctx, st, _cfg_kw(orc, 0.23, 3, exit_radius=5.0, reentry=0.75), order=order)
+    assert np.array_equal(g["nsub"], nsub) and list(nsub) == [6, 4, 1]
+    assert _rel_close(g["tco"], tco) and _rel_close(g["tcs"], tcs, scale=np.abs(tcs).max())
