@@ -1,13 +1,15 @@
 """Multi-GPU operation of ``cascade_amd.sim``: one process per GPU, ``torch.distributed``.
 
-Every process holds the same simulation. Propagation, sort and tree build run redundantly on
-each GPU (at 1M objects they take ~2 ms, less than moving the per-chunk boxes and records over
-xGMI would), the broad and narrow phases -- the bulk of a superstep -- are sharded over the
-query particles (``csc_set_shard``), and the only exchange is the per-step list of detected
-collisions and conjunctions: ``make_event_exchange`` builds the callable that
-``sim.set_shard(rank, nranks, exchange)`` expects. One small all-gather (the counts) per
-superstep; a second one only when some process found an event. Backend "nccl" (RCCL over xGMI)
-on GPUs, "gloo" in the CPU tests.
+Every process holds the same simulation. The broad and narrow phases are sharded over the pair
+tree (``csc_set_shard``), and the per-step lists of detected collisions and conjunctions are merged
+with one small all-gather (``make_event_exchange``; a second one only when some process found an
+event). By default propagation, sort and tree build run redundantly on each GPU (at 1M Kepler
+objects they take ~2 ms, less than moving the per-particle results over xGMI would);
+``shard(sim, propagation=True)`` shards the integration as well: every process integrates its own
+range of particles and ONE all-gather of 80 + 96 C bytes per particle (``make_device_gather``,
+in place on the simulation's device buffers) gives everybody the boxes, trajectory records, substep
+counts and final states -- worth it when the integration dominates the superstep (DESIGN.md
+section 7). Backend "nccl" (RCCL over xGMI) on GPUs, "gloo" in the tests.
 """
 import numpy as np
 
