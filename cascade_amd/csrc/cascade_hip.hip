@@ -76,6 +76,7 @@ struct csc_ctx {
     csc_conjunction *conj = nullptr;
     size_t conj_cap = 0, conj_count = 0;
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
+    int dt_levels = 0;          // levels with a non-empty frontier in the last dual traversal
     // csc_narrow_phase_prefilter -> csc_narrow_phase_finish: the candidate list left on the device
     const uint4 *np_cand_list = nullptr;
     uint64_t np_cand_count = 0;
@@ -1311,7 +1312,8 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         ctx->kt_begin("k_bp_dual");
         while (!done && level < DT_MAX_LEVELS) {
             // A batch of levels, then a look at the size of the frontier they left.
-            const int batch_end = std::min(DT_MAX_LEVELS, level + (level == 0 ? 32 : 8));
+            // (first batch: as many levels as the last traversal needed, plus one)
+            const int batch_end = std::min(DT_MAX_LEVELS, level + (level == 0 ? (ctx->dt_levels ? ctx->dt_levels + 1 : 32) : 8));
             for (; level < batch_end; ++level) {
                 q.level = static_cast<uint32_t>(level);
                 q.in = (level % 2 == 0) ? d_fa : d_fb;
@@ -1340,13 +1342,20 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         CSC_HIP(hipStreamSynchronize(ctx->stream));
         uint32_t max_fr = 0, max_pr = 0;
         uint64_t items = 0;
+        int used_levels = 0;
         for (int l = 0; l <= level; ++l) {
+            uint64_t at_level = 0;
             for (int s = 0; s < DT_SHARDS; ++s) {
                 const uint32_t v = hc[ctr_per_level * l + static_cast<size_t>(s) * DT_CTR_STRIDE];
                 max_fr = std::max(max_fr, v);
-                items += v;
+                at_level += v;
+            }
+            items += at_level;
+            if (at_level) {
+                used_levels = l + 1;
             }
         }
+        ctx->dt_levels = used_levels;
         ctx->bp_node_pairs = items;
         total = 0;
         for (int s = 0; s < DT_SHARDS; ++s) {
