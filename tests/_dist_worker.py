@@ -120,6 +120,17 @@ def main():
                 full.remove_particles([full.interrupt_info])
                 part.remove_particles([part.interrupt_info])
         assert nre >= 3
+
+        # Tape dynamics (the reference's default simple_earth: J2 + C22S22 + drag) over a range.
+        st, pars = leo_si_population(301, seed=9)
+        kw = dict(dyn=dynamics.simple_earth(), n_par_ct=4, reentry_radius=Re + 150e3)
+        full = sim(st.copy(), 185.5663, pars=pars.copy(), **kw)
+        part = shard(sim(st.copy(), 185.5663, pars=pars.copy(), **kw), propagation=True)
+        for _ in range(3):
+            of, op = full.step(), part.step()
+            assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
+            assert np.array_equal(full.state, part.state) and full.time == part.time
+            assert part.last_propagated <= 101
         print("simprop ok", rank)
     dist.barrier()
     dist.destroy_process_group()
