@@ -1711,7 +1711,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             for (int s = 0; s < csc::NP_FLAT_SHARDS; ++s) {
                 q.flat_cnt[s] = src.flat_cnt[s];
                 q.flat_tile_off[s] = flat_tiles;
-                flat_tiles += cdiv(src.flat_cnt[s], 64);
+                flat_tiles += cdiv(src.flat_cnt[s], csc::NP_FLAT_TILE);
             }
             q.flat_tile_off[csc::NP_FLAT_SHARDS] = flat_tiles;
         }
@@ -1736,9 +1736,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             CSC_HIP(hipMemcpyAsync(d_cnt + 5, &nc, sizeof(nc), hipMemcpyHostToDevice, ctx->stream));
         } else if (src.flat_pairs != nullptr) {
             if (src.srt_recs != nullptr) {
-                KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter_flat<true>), dim3(flat_tiles), dim3(64), 0, ctx->stream, q));
+                KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter_flat<true>), dim3(flat_tiles), dim3(csc::NP_FLAT_TILE), 0, ctx->stream, q));
             } else {
-                KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter_flat<false>), dim3(flat_tiles), dim3(64), 0, ctx->stream, q));
+                KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter_flat<false>), dim3(flat_tiles), dim3(csc::NP_FLAT_TILE), 0, ctx->stream, q));
             }
         } else if (src.srt_recs != nullptr) {
             KT("k_np_prefilter", hipLaunchKernelGGL((csc::k_np_prefilter<true>), dim3(src.norder * (csc::PB_SIZE / 64)), dim3(64), 0,

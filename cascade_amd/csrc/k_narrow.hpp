@@ -43,6 +43,7 @@ struct conj_rec {
 static_assert(sizeof(conj_rec) == 128, "conjunction layout");
 
 constexpr int NP_FLAT_SHARDS = 32; // = DT_SHARDS of k_bp_dual.hpp
+constexpr unsigned NP_FLAT_TILE = 256; // pairs per workgroup of k_np_prefilter_flat (4 waves: a quarter of the workgroup launches)
 
 struct np_params {
     std::uint32_t n;       // particles
@@ -66,7 +67,7 @@ struct np_params {
     const unsigned long long *flat_pairs;
     std::uint32_t flat_cap;
     std::uint32_t flat_cnt[NP_FLAT_SHARDS];          // pairs of each list
-    std::uint32_t flat_tile_off[NP_FLAT_SHARDS + 1]; // first 64-pair tile (= workgroup) of each list
+    std::uint32_t flat_tile_off[NP_FLAT_SHARDS + 1]; // first tile (= workgroup, NP_FLAT_TILE pairs) of each list
     const std::uint32_t *vidx;    // [C][n] sorted position -> original index
     const float4 *srt_recs;       // [C][n][4] sampled-trajectory records in sorted order
     double thr_extra;             // conjunction threshold (0 when conjunctions are not tracked)
@@ -597,17 +598,17 @@ __global__ __launch_bounds__(64) void k_np_prefilter(const np_params q)
 }
 
 // The same over the flat pair lists of the dual traversal (k_bp_dual.hpp): NP_FLAT_SHARDS lists
-// of packed pairs pos_a | pos_b << 28 | chunk << 56; workgroup w handles 64 pairs of the shard
+// of packed pairs pos_a | pos_b << 28 | chunk << 56; workgroup w handles NP_FLAT_TILE pairs of the shard
 // whose tile range [flat_tile_off[s], flat_tile_off[s + 1]) contains w.
 template <bool FILTER>
-__global__ __launch_bounds__(64) void k_np_prefilter_flat(const np_params q)
+__global__ __launch_bounds__(NP_FLAT_TILE) void k_np_prefilter_flat(const np_params q)
 {
     const std::uint32_t wg = blockIdx.x;
     int s = 0;
     while (s + 1 < NP_FLAT_SHARDS && wg >= q.flat_tile_off[s + 1]) {
         ++s;
     }
-    const std::uint32_t t = (wg - q.flat_tile_off[s]) * 64u + threadIdx.x;
+    const std::uint32_t t = (wg - q.flat_tile_off[s]) * NP_FLAT_TILE + threadIdx.x;
     if (t >= q.flat_cnt[s]) {
         return;
     }
