@@ -1257,7 +1257,9 @@ outcome sim::step()
         d.chk(csc_narrow_phase_prefilter(ctx, n, nchunks, m_conj_thresh, d_srecs, &ncand));
         auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
         d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, nullptr));
-        nrows = static_cast<std::uint64_t>(nlist) * summ.max_substeps; // (an upper bound is enough)
+        // (an upper bound is enough: the listed particles times the largest substep count, and
+        // never more than the substeps of all particles)
+        nrows = std::min<std::uint64_t>(static_cast<std::uint64_t>(nlist) * summ.max_substeps, tot);
         if (static_cast<std::uint64_t>(nlist) * 4u > n || d.want_full_rows) {
             store_all();
         } else {
