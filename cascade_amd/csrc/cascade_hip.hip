@@ -1278,7 +1278,13 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
     uint32_t fr_cap = std::max<uint32_t>({ctx->dt_fr_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 4u, 4096u});
     uint32_t pair_cap = std::max<uint32_t>({ctx->dt_pair_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u});
     std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 2));
-    const unsigned grid = DT_SHARDS * 64u; // 2048 workgroups of 256: 8 per CU
+    // Workgroups per shard (each strides over the 256-item tiles of its shard): 256, i.e. 8192
+    // workgroups in all, measured best at 1M objects (1.65 ms with 64, 1.47 with 256, 1.53 with
+    // 1024: more of them hide the gather latency better until the empty ones of the small levels
+    // cost more); 64 for small populations. CASCADE_DT_GRID overrides (measurements).
+    const unsigned per_shard = std::getenv("CASCADE_DT_GRID") ? std::max(1, std::atoi(std::getenv("CASCADE_DT_GRID")))
+                                                              : (static_cast<uint64_t>(n) * nchunks >= 200000u ? 256u : 64u);
+    const unsigned grid = DT_SHARDS * per_shard;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
         CSC_BUF(d_fa, unsigned long long, "dt_frontier_a", static_cast<size_t>(fr_cap) * DT_SHARDS);
