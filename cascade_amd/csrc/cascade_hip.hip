@@ -1278,12 +1278,14 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
     uint32_t fr_cap = std::max<uint32_t>({ctx->dt_fr_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 4u, 4096u});
     uint32_t pair_cap = std::max<uint32_t>({ctx->dt_pair_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u});
     std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 2));
-    // Workgroups per shard (each strides over the 256-item tiles of its shard): 256, i.e. 8192
-    // workgroups in all, measured best at 1M objects (1.65 ms with 64, 1.47 with 256, 1.53 with
-    // 1024: more of them hide the gather latency better until the empty ones of the small levels
-    // cost more); 64 for small populations. CASCADE_DT_GRID overrides (measurements).
+    // Workgroups per shard (each strides over the DT_BLOCK-item tiles of its shard): 512 of 128
+    // threads, i.e. 16384 workgroups in all, measured best at 1M objects (per traversal: 1.65 ms
+    // with 64 x 256 threads, 1.47 with 256 x 256, 1.42 with 512 x 128, 1.45 with 1024 x 128, 1.47
+    // with 1024 x 64: more, smaller workgroups balance the load and hide the gather latency better
+    // until the empty ones of the small levels cost more); 128 for small populations.
+    // CASCADE_DT_GRID overrides (measurements).
     const unsigned per_shard = std::getenv("CASCADE_DT_GRID") ? std::max(1, std::atoi(std::getenv("CASCADE_DT_GRID")))
-                                                              : (static_cast<uint64_t>(n) * nchunks >= 200000u ? 256u : 64u);
+                                                              : (static_cast<uint64_t>(n) * nchunks >= 200000u ? 512u : 128u);
     const unsigned grid = DT_SHARDS * per_shard;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {

@@ -19,7 +19,7 @@
 // dependent loads), 2: multi-particle leaf (value = canonical index; rare: equal Morton codes),
 // a thread expands one item: the (up to four) child pairs with overlapping boxes go to the
 // next frontier, leaf-leaf pairs to the pair list. Both outputs are compacted per workgroup
-// (ballot-free block scan, one atomic per 256 items and output kind) into DT_SHARDS independent
+// (ballot-free block scan, one atomic per DT_BLOCK items and output kind) into DT_SHARDS independent
 // regions, each with its own counter on its own cache line: same-address atomics from
 // thousands of workgroups serialise at ~13 ns each.
 //
@@ -38,7 +38,7 @@
 namespace csc
 {
 
-constexpr int DT_BLOCK = 256;
+constexpr int DT_BLOCK = 128;
 constexpr int DT_SHARDS = 32;
 constexpr int DT_CTR_STRIDE = 16; // u32 counters 64 bytes apart
 constexpr int DT_MAX_LEVELS = 2 * BVH_MAX_LEVELS + 2;
