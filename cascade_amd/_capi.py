@@ -131,6 +131,7 @@ SYMBOLS = {
     "csc_candidate_objects": (_i32, [_vp, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_u64)]),
     "csc_narrow_phase_finish": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 7 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
     "csc_narrow_phase_candidates": (_u64, [_vp]),
+    "csc_narrow_phase_attempts": (C.c_uint32, [_vp]),
     "csc_narrow_phase_pairs": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 9 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
     "csc_narrow_phase_get": (_i32, [_vp, _vp, _u64, _vp, _u64]),
     "csc_dense_propagate": (_i32, [_vp, _u32, _u32, _dbl] + [_vp] * 6),

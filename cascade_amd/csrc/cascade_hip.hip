@@ -76,6 +76,7 @@ struct csc_ctx {
     csc_conjunction *conj = nullptr;
     size_t conj_cap = 0, conj_count = 0;
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
+    uint32_t np_attempts = 0;   // passes the last narrow-phase call needed (1 = no list overflowed)
     int dt_levels = 0;          // levels with a non-empty frontier in the last dual traversal
     // csc_narrow_phase_prefilter -> csc_narrow_phase_finish: the candidate list left on the device
     const uint4 *np_cand_list = nullptr;
@@ -1679,7 +1680,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
     uint32_t h[8];
     // The lists feed each other (candidates -> survivors / deferred -> events), so an overflow
     // upstream hides the true size downstream: up to one retry per list, plus slack.
+    ctx->np_attempts = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
+        ctx->np_attempts = static_cast<uint32_t>(attempt) + 1u;
         CSC_BUF(d_coll, csc::coll_rec, "np_coll", coll_cap);
         CSC_BUF(d_conj, csc::conj_rec, "np_conj", conj_cap);
         CSC_BUF(d_surv, uint4, "np_surv", static_cast<size_t>(surv_cap) * 2u);
@@ -2038,6 +2041,11 @@ int csc_narrow_phase_finish(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double c
 uint64_t csc_narrow_phase_candidates(csc_ctx *ctx)
 {
     return ctx->np_candidates;
+}
+
+uint32_t csc_narrow_phase_attempts(csc_ctx *ctx)
+{
+    return ctx->np_attempts;
 }
 
 int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, csc_conjunction *conj,

@@ -1240,7 +1240,7 @@ outcome sim::step()
     }
     pt.lap("sort/bvh/bp");
     std::uint64_t ncoll = 0, nconj = 0;
-    std::uint32_t warn = 0;
+    std::uint32_t warn = 0, np_attempts = 0;
     // Taylor coefficients for dense output when the integration did not write them: exact-fit CSR
     // rows, of every particle in the Morton order of chunk 0 (two-pass mode), or only of the
     // particles that the candidate pairs involve.
@@ -1255,6 +1255,7 @@ outcome sim::step()
         std::uint64_t ncand = 0, nrows = 0;
         std::uint32_t nlist = 0;
         d.chk(csc_narrow_phase_prefilter(ctx, n, nchunks, m_conj_thresh, d_srecs, &ncand));
+        np_attempts += csc_narrow_phase_attempts(ctx) - 1u;
         auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
         d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, nullptr));
         // (an upper bound is enough: the listed particles times the largest substep count, and
@@ -1294,6 +1295,7 @@ outcome sim::step()
     d.stats.bp_pairs = npairs;
     d.stats.bp_node_pairs = csc_broad_phase_node_pairs(ctx);
     d.stats.np_candidates = csc_narrow_phase_candidates(ctx);
+    d.stats.np_attempts = np_attempts + csc_narrow_phase_attempts(ctx);
     d.stats.total_substeps = tot;
     d.stats.nchunks = nchunks;
     d.last_coll.clear();

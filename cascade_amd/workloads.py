@@ -160,3 +160,76 @@ def haumea_dynamics():
         dyn[3 + k] = (lhs, rhs + mu_s * ((qs - q) * dps - qs * dcs) + D.diff(vell, q))
     consts = dict(G=G, m_c=m_c, mu_c=mu_c, ra=ra, rb=rb, rc=rc, Ac=Ac, Bc=Bc, Cc=Cc, mu_s=mu_s, a_s=a_s, e_s=e_s, inc_s=inc_s)
     return dyn, consts
+
+
+def leo_shells(nparts, seed=42):
+    """BASELINE configs[3]: objects in Walker-like shells: semi-major axes
+    {1.08, 1.09, 1.17, 1.19} +- 0.002 Earth radii, inclinations {53, 70, 97.6} +- 0.5 degrees,
+    e < 1e-3, uniform angles, size 1e-7; normalised Kepler units (mu = 1). Meant to be run with
+    conj_thresh = 7.8e-4 (5 km) and min_coll_radius = inf. Returns state [nparts, 7]."""
+    rng = np.random.default_rng(seed)
+    n = nparts
+    a = rng.choice([1.08, 1.09, 1.17, 1.19], n) + rng.uniform(-0.002, 0.002, n)
+    inc = np.deg2rad(rng.choice([53.0, 70.0, 97.6], n) + rng.uniform(-0.5, 0.5, n))
+    x, v = kep_to_cart_bench(a, rng.uniform(0, 1e-3, n), inc, rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n))
+    return np.ascontiguousarray(np.concatenate([x, v, np.full((n, 1), 1e-7)], axis=1))
+
+
+def load_leo_2022(path):
+    """The 19 647-object catalogue of benchmark/2022_leo_pop.cpp:197-209 from a .npz made by
+    tests/golden/make_fixtures.py (the data files themselves are the reference's:
+    benchmark/data/test_ic_19647.txt, test_par_19647.txt, best_fit_density.txt). Returns
+    (state [n, 7], bstar [n, 1], best_fit_density [12])."""
+    d = np.load(path)
+    return np.ascontiguousarray(d["state"]), np.ascontiguousarray(d["bstar"]), np.array(d["best_fit_density"])
+
+
+def leo_2022_dynamics(best_x):
+    """The dynamics of benchmark/2022_leo_pop.cpp:218-287 in its own form, written with
+    cascade_amd.dynamics expressions (runs from the tape): Kepler + J2 from C20 (:228-238), C22/S22
+    in the rotating frame (:240-272), drag with the 4-term density fit best_x (:80-91, :274-284);
+    like the driver, the C22 force enters a second time together with the drag term (:285-287).
+    Returns (dyn, constants); par[0] = BSTAR, reentry at Re + 150 km (:223, :297)."""
+    from . import dynamics as D
+
+    GMe, C20, C22, S22, Re = 398600441800000.0, -4.84165371736e-4, 2.43914352398e-6, -1.40016683654e-6, 6378137.0
+    pi = float(np.pi)
+    x, y, z, vx, vy, vz = D.make_vars("x", "y", "z", "vx", "vy", "vz")
+    dyn = D.kepler(GMe)
+    magr2 = x * x + y * y + z * z
+    J2term1 = GMe * (Re * Re) * float(np.sqrt(5.0)) * C20 / (2.0 * D.sqrt(magr2))
+    J2term2 = 3.0 / (magr2 * magr2)
+    J2term3 = 15.0 * (z * z) / (magr2 * magr2 * magr2)
+    fJ2 = (J2term1 * x * (J2term2 - J2term3), J2term1 * y * (J2term2 - J2term3), J2term1 * z * (3.0 * J2term2 - J2term3))
+
+    theta_g = (pi / 180) * 280.4606
+    nu_e = (pi / 180) * 4.178074622024230e-3
+    ang = theta_g + nu_e * D.time
+    ca, sa = D.cos(ang), D.sin(ang)
+    X, Y, Z = x * ca + y * sa, -x * sa + y * ca, z
+    s15 = float(np.sqrt(15.0))
+    C22term1 = 5.0 * GMe * (Re * Re) * s15 * C22 / (2.0 * D.pow(magr2, 7.0 / 2))
+    C22term2 = GMe * (Re * Re) * s15 * C22 / D.pow(magr2, 5.0 / 2)
+    fC22X = C22term1 * X * (Y * Y - X * X) + C22term2 * X
+    fC22Y = C22term1 * Y * (Y * Y - X * X) - C22term2 * Y
+    fC22Z = C22term1 * Z * (Y * Y - X * X)
+    S22term1 = 5 * GMe * (Re * Re) * s15 * S22 / D.pow(magr2, 7.0 / 2)
+    S22term2 = GMe * (Re * Re) * s15 * S22 / D.pow(magr2, 5.0 / 2)
+    fS22X = -S22term1 * (X * X) * Y + S22term2 * Y
+    fS22Y = -S22term1 * X * (Y * Y) + S22term2 * X
+    fS22Z = -S22term1 * X * Y * Z
+    fC22 = (fC22X * ca - fC22Y * sa, fC22X * sa + fC22Y * ca, fC22Z)
+    fS22 = (fS22X * ca - fS22Y * sa, fS22X * sa + fS22Y * ca, fS22Z)
+
+    magv = D.sqrt(vx * vx + vy * vy + vz * vz)
+    altitude = D.sqrt(magr2) - Re
+    density = None
+    for i in range(4):
+        alpha, beta, gamma = float(best_x[i]), float(best_x[i + 4]) / 1000, float(best_x[i + 8]) * 1000
+        term = alpha * D.exp(-(altitude - gamma) * beta)
+        density = term if density is None else density + term
+    fdrag = density / (0.1570 / Re) * D.par[0] * magv
+    for k, v in enumerate((vx, vy, vz)):
+        lhs, rhs = dyn[3 + k]
+        dyn[3 + k] = (lhs, rhs + fJ2[k] + (fC22[k] + fS22[k]) + (fC22[k] + (-fdrag * v)))
+    return dyn, dict(GMe=GMe, Re=Re, reentry_radius=Re + 150000.0, ct=185.5663, n_par_ct=30)

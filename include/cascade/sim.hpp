@@ -212,6 +212,7 @@ public:
         std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles
         std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)
+        std::uint32_t np_attempts = 0;    // narrow-phase passes (more than one per call: an output list overflowed and was grown)
     };
 
 private:

@@ -313,6 +313,11 @@ int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, doub
                      const double *d_tcs_vr, const double *d_tcoords, const float *d_srt_recs, uint64_t *n_coll,
                      uint64_t *n_conj, uint32_t *warn_flags);
 uint64_t csc_narrow_phase_candidates(csc_ctx *ctx);
+/* Diagnostic: passes the last narrow-phase call made over its lists. The reference grows
+ * concurrent vectors (src/sim_narrow_phase.cpp:985-1011); here the output lists have capacities
+ * that follow the previous superstep, and a list that overflows is grown and the pass repeated
+ * (results are recomputed from scratch). 1 = nothing overflowed. */
+uint32_t csc_narrow_phase_attempts(csc_ctx *ctx);
 /* The same narrow phase in two calls, for callers that produce the Taylor rows on demand: the
  * reference stores the rows of every particle (the propagate callback, src/sim_propagate.cpp:710-755)
  * although narrow_phase_parallel (src/sim_narrow_phase.cpp:495-1023) reads only those of the pairs

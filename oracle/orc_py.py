@@ -229,7 +229,9 @@ class Sim:
             rhs = np.ascontiguousarray(tape["rhs"], dtype=np.int32)
             if L.orc_sim_set_tape(self._h, _p(ops), len(ops), int(tape["nslots"]), _p(rhs), int(tape["npars"])) != 0:
                 raise OracleError(L.orc_last_error().decode())
+        self._pars = None
         if pars is not None:
+            self._pars = np.array(pars, dtype=np.float64).reshape(st.shape[0], -1)
             # dyn_kind bit 1 (drag): pars[:, 0] = BSTAR; dens = the 12 density-fit constants or None
             pr = np.ascontiguousarray(np.asarray(pars, dtype=np.float64).reshape(-1))
             d12 = None if dens is None else np.ascontiguousarray(np.asarray(dens, dtype=np.float64).reshape(12))
@@ -270,6 +272,18 @@ class Sim:
     def set_new_state(self, st):
         st = np.ascontiguousarray(np.asarray(st, dtype=np.float64).reshape(-1, 7))
         self._chk(self._L.orc_sim_set_state(self._h, _p(st), st.shape[0]))
+
+    def remove_particles(self, idx):
+        """Drops the particles idx (state rows and their runtime parameters), keeping the order
+        of the others: the caller pattern of benchmark/2022_leo_pop.cpp:311-337."""
+        keep = np.ones(self.nparts, dtype=bool)
+        keep[np.asarray(list(idx), dtype=np.int64)] = False
+        st = self.state[keep]
+        if self._pars is not None:
+            self._pars = np.ascontiguousarray(self._pars[keep])
+            pr = self._pars.reshape(-1)
+            self._chk(self._L.orc_sim_set_pars(self._h, _p(pr), pr.size, None))
+        self.set_new_state(st)
 
     def poke_state(self, st):
         st = np.ascontiguousarray(np.asarray(st, dtype=np.float64).reshape(-1, 7))
