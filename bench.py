@@ -2,24 +2,28 @@
 """bench.py -- object-days propagated per second, collision detection included.
 
 Workload (BASELINE.json configs[1]): the random LEO Kepler population of
-benchmark/random_leo_pop_kep.cpp scaled to 1,000,000 objects on one MI355X, ct = 0.23,
-n_par_ct = 1, Keplerian dynamics mu = 1 (1 TU = 806.81 s). A "step" is one sim.step()
-(propagate -> AABB -> Morton -> sort -> BVH -> broad phase -> narrow phase -> outcome)
-with the state already resident in HBM.
+benchmark/random_leo_pop_kep.cpp scaled to 1,000,000 objects, ct = 0.23, n_par_ct = 1, Keplerian
+dynamics mu = 1 (1 TU = 806.81 s). A "step" is one sim.step() (propagate -> AABB -> Morton ->
+sort -> BVH -> broad phase -> narrow phase -> outcome) with the state already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, ONE 1M-object simulation sharded over the N GPUs (strong
-scaling): every rank propagates all objects and builds the whole BVH (cheaper than moving the
-boxes over xGMI at this size), walks it for its share of the query objects, runs the narrow
-phase on its pairs, and the per-step event lists are all-gathered with RCCL
-(cascade_amd/parallel.py). --mode replicas runs N independent
-simulations instead (weak scaling, no collective).
+ONE experiment at every N: one 1M-object simulation (strong scaling). At N > 1 it is sharded the
+way BASELINE.json's north_star says: every rank integrates its own range of objects, one RCCL
+all-gather moves the per-object records (boxes, trajectory records, final states), every rank
+sorts and builds the tree, expands its share of the pair tree and runs the narrow phase on its
+pairs; conjunction records stay on the rank that found them, collisions and the earliest event are
+exchanged (cascade_amd/parallel.py). --replicate-propagation keeps the
+integration on every rank instead; --mode replicas runs N independent simulations (weak scaling,
+no collective; not the default).
 
-Prints ONE JSON line (rank 0) with the contract fields plus "roofline" (dominant kernel,
-algorithmic bytes / HIP-event kernel time) and, at N = 1, "cpu_baseline" (the CPU oracle,
-an OpenMP port of the reference's algorithms, timed on a bounded sample on this host).
+Prints ONE JSON line (rank 0): the contract fields, "roofline" (dominant kernel: SURVEY 8(d)'s
+algorithmic bytes / its HIP-event duration inside the timed region), "roofline_other_kernels",
+"ms_per_step_host_sync" (the default mode of the drop-in class: host arrays authoritative at
+every step) and, at N = 1, "cpu_baseline": the CPU oracle (an OpenMP port of the reference's
+algorithms) timed on the SAME supersteps from the SAME state, after asserting that it and the GPU
+agree on outcomes, pair counts, event lists and final states.
 """
 import argparse
 import json
@@ -34,27 +38,60 @@ import numpy as np  # noqa: E402
 
 TU_SECONDS = 806.81  # test/last_bit_flip.cpp:61
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VEC_PEAK_TFLOPS = 78.6
+FP64_VEC_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
+P = 20  # Taylor order at tol = DBL_EPSILON
 
-# Algorithmic bytes per unit, P = 20: what the reference's algorithm has to move
-# per unit, not what this implementation happens to fetch.
+
+def taylor_flops(dyn="kepler", p=P):
+    """FP64 flops of ONE object-substep: the Taylor recurrences of orders 0..p-1 for the given
+    dynamics exactly as cascade_amd/csrc/k_propagate.hpp::dyn_order runs them (= oracle/orc.hpp::
+    compute_tcs; an FMA counts 2, a division or square root 1), plus the Horner update of the 7
+    state variables (7 * 2p). Step-size control, event polynomials and the AABB
+    Horner are not counted."""
+    conv = lambda n: 2 * (n + 1)  # noqa: E731  n + 1 FMAs
+
+    def sq(n):  # conv_sq: symmetric half-sum
+        return 1 if n == 0 else 2 * ((n + 1) // 2) + 1 + (2 if n % 2 == 0 else 0)
+
+    tot = 0
+    for n in range(p):
+        f = 3 * sq(n) + 2  # u = x^2 + y^2 + z^2
+        f += 4 if n == 0 else 3 * n + 2  # w = u^(-3/2)
+        f += 3 * (conv(n) + 1)  # -mu x w ...
+        f += 3 * conv(n) + 2 + 3 * n + 1  # r' = (x vx + y vy + z vz) / r
+        f += 7  # x^[n+1] = rhs^[n] / (n + 1)
+        if dyn in ("j2", "j2drag"):
+            f += (2 * n + 2) + conv(n) + sq(n) + (conv(n) + 1) + 2 * (conv(n) + 2) + 3 * (conv(n) + 1)
+        if dyn == "j2drag":
+            f += 2 * max(n - 1, 0) + 1  # sqrt(u)
+            f += 4 * (4 * n + 1) + 8  # four exponentials + density sum
+            f += 3 * sq(n) + 2 + 2 * max(n - 1, 0) + 1  # |v|^2, |v|
+            f += conv(n) + 1 + 3 * (conv(n) + 1)  # drag force
+        tot += f
+    return tot + 7 * 2 * p
+
+
+# Algorithmic bytes per launch (SURVEY 8(d)), P = 20: what the reference's algorithm has to move per
+# unit, not what this implementation happens to fetch.
 BYTES = {
-    "k_propagate_store": lambda u: u["substeps"] * (1176 + 16) + u["n"] * 56,
-    "k_propagate": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28),
-    "k_np_fex": lambda u: u["pair_intervals"] * 1008,
+    "k_propagate_store": lambda u: u["stored_substeps"] * (1176 + 16) + u["stored_objects"] * 56,
+    # K1 without rows + K2 fused: state in, final state + boxes + (new) trajectory records out
+    "k_propagate": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28 + 64 * u["nchunks"]),
+    "k_np_fex": lambda u: u["np_candidates"] * 1008,
     "k_broad_phase": lambda u: u["bp_nodes_visited"] * 44 + u["pairs"] * 8,
-    # Dual traversal: per expanded node pair two node records of 44 B (box + links, the figure SURVEY
-    # 8d uses per node visit) and one frontier item in, one out (8 B each); 8 B per output pair.
-    "k_bp_dual": lambda u: u["bp_node_pairs"] * (2 * 44 + 16) + u["pairs"] * 8,
+    # K6 = 44 B x nodes visited + 8 B x pairs; the dual traversal visits two nodes per node pair.
+    "k_bp_dual": lambda u: u["bp_node_pairs"] * 2 * 44 + u["pairs"] * 8,
+    "k_np_prefilter": lambda u: u["pairs"] * (8 + 128),
     "k_rs_scatter": lambda u: u["sort_keys"] * 24,
     "k_rs_hist": lambda u: u["sort_keys"] * 8,
+    "k_gather_aabb": lambda u: u["n"] * u["nchunks"] * 2 * (32 + 64),
+    "k_bvh_refit": lambda u: u["n"] * u["nchunks"] * 2 * 2 * 32,  # every node's box written once, read once
 }
 
 
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary under profiles/
-    (profiles/summarise.py: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, plus
-    WRITE_SIZE) whose workload string matches this run; None otherwise."""
+    (profiles/summarise.py) whose workload string matches this run; None otherwise."""
     import glob
 
     best = None
@@ -64,7 +101,7 @@ def measured_traffic(kernel, workload):
         except Exception:
             continue
         if d.get("workload") == workload and kernel in d.get("kernels", {}):
-            best = (d["kernels"][kernel]["traffic_bytes"], os.path.basename(path))
+            best = (d["kernels"][kernel], os.path.basename(path))
     return best
 
 
@@ -77,17 +114,17 @@ def main():
     ap.add_argument("--ct", type=float, default=0.23)
     ap.add_argument("--n-par-ct", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-host-sync-leg", action="store_true")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded")
-    ap.add_argument("--shard-propagation", action="store_true",
-                    help="sharded mode: every rank integrates only its range of objects (one all-gather of 176 B per object and "
-                    "superstep); off by default: for 1M Kepler objects the replicated integration (0.4 ms) is cheaper")
+    ap.add_argument("--replicate-propagation", action="store_true",
+                    help="N > 1: every rank integrates all objects (no all-gather of the per-object records)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    backend = None
     if world > 1:
         import torch
         import torch.distributed as dist_
@@ -106,12 +143,14 @@ def main():
 
     N = args.nparts
     sharded = world > 1 and args.mode == "sharded"
-    st = random_leo_pop_kep(N, seed=42 if (sharded or world == 1) else 42 + rank)
+    replicas = world > 1 and not sharded
+    shard_prop = sharded and not args.replicate_propagation
+    st = random_leo_pop_kep(N, seed=42 + rank if replicas else 42)
     s = sim(st, args.ct, n_par_ct=args.n_par_ct, device=local_rank)
     if sharded:
         from cascade_amd.parallel import shard
 
-        shard(s, propagation=args.shard_propagation)
+        shard(s, propagation=shard_prop)
     s.host_sync = False  # state stays resident in HBM between steps
     s.upload_state()
     ctx = _capi.Context.from_handle(s._hip_context)  # the simulation's C-ABI context (profiling only)
@@ -139,7 +178,13 @@ def main():
     dom = max(survey, key=lambda k: survey[k][1])
     ctx.profile_only(dom)
     ctx.profile_reset()
+    # The state the timed region starts from (for the CPU leg, which runs the same supersteps).
+    st_w, t_w = None, s.time
+    if world == 1 and not args.no_cpu_baseline:
+        s.download_state()
+        st_w = np.array(s.state)
     pairs = 0
+    pairs_by_step = []
     outcomes = {}
     t_sim0 = s.time
     barrier()
@@ -148,6 +193,7 @@ def main():
         oc = s.step()
         outcomes[oc.name] = outcomes.get(oc.name, 0) + 1
         pairs += s.last_bp_pairs
+        pairs_by_step.append(s.last_bp_pairs)
     barrier()
     wall = time.perf_counter() - t0
     prof = ctx.profile_get()
@@ -157,21 +203,26 @@ def main():
 
     wall_max = wall
     tot_obj_days = N * sim_time * TU_SECONDS / 86400.0
+    propagated = s.last_propagated
     if dist is not None:
         import torch
 
         t = torch.tensor([wall], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max = float(t.item())
-        if not sharded:
+        if replicas:
             od = torch.tensor([tot_obj_days], dtype=torch.float64, device=tdev)
             dist.all_reduce(od, op=dist.ReduceOp.SUM)
             tot_obj_days = float(od.item())
-        pr = torch.tensor([float(pairs)], dtype=torch.float64, device=tdev)
-        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
-        pairs_all = float(pr.item())
+        pr = torch.tensor([float(pairs), float(propagated)], dtype=torch.float64, device=tdev)
+        gathered = [torch.zeros_like(pr) for _ in range(world)]
+        dist.all_gather(gathered, pr)
+        per_rank_pairs = [float(g[0].item()) / args.steps for g in gathered]
+        per_rank_prop = [int(g[1].item()) for g in gathered]
     else:
-        pairs_all = float(pairs)
+        per_rank_pairs = [pairs / args.steps]
+        per_rank_prop = [int(propagated)]
+    pairs_all = sum(per_rank_pairs)
 
     if rank != 0:
         if dist is not None:
@@ -179,36 +230,69 @@ def main():
         return
 
     value = tot_obj_days / wall_max
-    # Dominant kernel + roofline from the HIP-event timings of the timed region.
     # kern: per-kernel (launches, ms) scaled to the timed steps: the dominant kernel from the
     # timed region itself, the others from the survey.
     kern = {k: (v[0] * args.steps / nsurvey, v[1] * args.steps / nsurvey) for k, v in survey.items()}
     kern[dom] = prof[dom]
     tot_kernel_ms = sum(v[1] for v in kern.values())
-    # Units of the last step (populations change slowly; the counts of all steps agree to <0.1 %).
-    units = dict(n=N, nchunks=args.n_par_ct, substeps=s.last_total_substeps, pairs=pairs / args.steps, pair_intervals=pairs / args.steps * max(1.0, s.last_total_substeps / (N * args.n_par_ct)), sort_keys=N * args.n_par_ct, bp_nodes_visited=s.bp_nodes_visited(), bp_node_pairs=s.last_bp_node_pairs)
-    if sharded:
-        workload = "random_leo_pop_kep scaled to %d objects, one simulation over %d GPUs (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42)" % (N, world, args.ct, args.n_par_ct)
+    # Units of one superstep of this rank (populations change slowly; the counts of all steps agree to <0.1 %).
+    store_launches = max(kern.get("k_propagate_store", (0, 0))[0] / args.steps, 0)
+    units = dict(
+        n=int(propagated),
+        nchunks=args.n_par_ct,
+        substeps=s.last_total_substeps * propagated / N,
+        pairs=pairs / args.steps,
+        np_candidates=s.last_np_candidates,
+        stored_objects=s.last_stored_objects,
+        stored_substeps=s.last_stored_objects * max(1.0, s.last_total_substeps / N),
+        sort_keys=N * args.n_par_ct,
+        bp_node_pairs=s.last_bp_node_pairs,
+        bp_nodes_visited=0,
+    )
+    if dom == "k_broad_phase":
+        units["bp_nodes_visited"] = s.bp_nodes_visited()
+    if replicas:
+        workload = "random_leo_pop_kep scaled to %d objects per GPU, %d independent simulations (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, world, args.ct, args.n_par_ct)
     else:
-        workload = "random_leo_pop_kep scaled to %d objects per GPU (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42+rank)" % (N, args.ct, args.n_par_ct)
+        workload = "random_leo_pop_kep scaled to %d objects, one simulation on %d GPU(s) (Kepler mu=1, ct=%g, n_par_ct=%d, seed 42)" % (N, world, args.ct, args.n_par_ct)
 
     def roofline_of(name):
         launches, ms = kern[name]
         per_step_launches = launches / args.steps
         avg_ms = ms / launches
         r = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, avg_launch_ms=round(avg_ms, 5))
+        alg_bytes = None
         if name in BYTES:
-            alg_bytes_per_launch = BYTES[name](units) / per_step_launches
-            achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            r.update(achieved=round(achieved, 2), frac=round(achieved / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(alg_bytes_per_launch))
+            alg_bytes = BYTES[name](units) / per_step_launches
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            r.update(achieved=round(achieved, 2), frac=round(achieved / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(alg_bytes))
+        if name == "k_propagate":
+            # report against the FP64 vector peak AND the HBM figure; the bound that
+            # takes longer at its peak is the binding one.
+            fl = taylor_flops("kepler") * units["substeps"] / per_step_launches
+            tf = fl / (avg_ms * 1e-3) / 1e12
+            r["fp64"] = dict(flops_per_object_substep=taylor_flops("kepler"), flops_per_launch=int(fl), achieved_TFLOPs=round(tf, 3), peak_TFLOPs=FP64_VEC_PEAK_TFLOPS, frac=round(tf / FP64_VEC_PEAK_TFLOPS, 5))
+            t_f, t_b = fl / (FP64_VEC_PEAK_TFLOPS * 1e12), (alg_bytes or 0) / (HBM_PEAK_GBS * 1e9)
+            if t_f >= t_b:
+                r.update(bound="fp64_valu", achieved=round(tf, 3), peak=FP64_VEC_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_VEC_PEAK_TFLOPS, 5), hbm_frac=round(t_b / (avg_ms * 1e-3), 5))
         t = measured_traffic(name, workload)
         if t is not None:
-            r.update(traffic=t[0], traffic_source="profiles/" + t[1], traffic_GBps=round(t[0] / (avg_ms * 1e-3) / 1e9, 1))
+            tb = t[0]["traffic_bytes"]
+            r.update(traffic=tb, traffic_source="profiles/" + t[1], traffic_GBps=round(tb / (avg_ms * 1e-3) / 1e9, 1), traffic_note=t[0].get("note"))
         return r
 
     roof = roofline_of(dom)
-    roof["units"] = {k: v for k, v in units.items()}
-    other_roofs = [roofline_of(k) for k in sorted(kern, key=lambda k: -kern[k][1])[1:4] if k in BYTES]
+    roof["units"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in units.items()}
+    other_roofs = [roofline_of(k) for k in sorted(kern, key=lambda k: -kern[k][1])[1:6] if k in BYTES]
+
+    if replicas:
+        parallelism = "replicas x%d (independent simulations, no collective)" % world
+    elif world == 1:
+        parallelism = "one simulation, one GPU"
+    elif shard_prop:
+        parallelism = "one simulation: propagation sharded x%d, one RCCL all-gather of the per-object records, replicated sort / BVH, pair tree and narrow phase sharded x%d, conjunction records rank-local, collisions + earliest event exchanged" % (world, world)
+    else:
+        parallelism = "one simulation: replicated propagation / sort / BVH, pair tree and narrow phase sharded x%d, conjunction records rank-local, collisions + earliest event exchanged" % world
 
     out = {
         "metric": "object-days propagated/sec incl. collision detection",
@@ -219,20 +303,24 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall_max / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if sharded else "weak",
+        "scaling": "weak" if replicas else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": workload,
-            "nparts_per_gpu": N,
+            "nparts": N,
             "ct": args.ct,
             "n_par_ct": args.n_par_ct,
-            "parallelism": (("one simulation, propagation and queries sharded x%d (per-object records all-gathered, replicated sort / BVH, events all-gathered over RCCL)" % world if args.shard_propagation else "one simulation, queries sharded x%d (replicated propagation / sort / BVH, events all-gathered over RCCL)" % world)) if sharded else "replicas x%d" % world,
-            "bp_pairs_per_step_all_ranks": pairs_all / args.steps,
+            "parallelism": parallelism,
+            "backend": backend,
+            "ranks": world,
+            "propagated_per_rank": per_rank_prop,
+            "bp_pairs_per_step_per_rank": per_rank_pairs,
+            "bp_pairs_per_step_all_ranks": pairs_all,
             "outcomes": outcomes,
-            "bp_pairs_per_step": pairs / args.steps,
             "sim_time_advanced_TU": sim_time,
+            "state": "resident in HBM between steps (host_sync off)",
         },
         "roofline": roof,
         "roofline_other_kernels": other_roofs,
@@ -241,42 +329,75 @@ def main():
         "kernel_ms_total_per_step": round(tot_kernel_ms / args.steps, 4),
     }
 
+    if world == 1 and not args.no_host_sync_leg:
+        # The default mode of the drop-in class (cascade.py/core.cpp:199-230 hands out writable views
+        # of the host arrays): state up / down around every step. Not part of `value`.
+        s.host_sync = True
+        s.step()
+        k = max(3, min(args.steps, 10))
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            s.step()
+        ctx.sync()
+        out["ms_per_step_host_sync"] = round((time.perf_counter() - t1) / k * 1e3, 4)
+        s.host_sync = False
+
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"] = cpu_baseline(args, st_w, t_w, pairs_by_step)
 
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args):
-    """The CPU oracle (oracle/: an OpenMP port of the reference's algorithms, kind "port")
-    timed on a bounded sample of the same workload: the first cpu_sample objects (default: all
-    of them) of the same seeded population, 2 steps after 1 warm-up step: about 20 s of CPU
-    work on 16 cores at 1M objects. The broad/narrow phase cost per object grows with the
-    population density, so a smaller sample would overstate the CPU rate."""
-    from cascade_amd.workloads import random_leo_pop_kep
+def cpu_baseline(args, st_w, t_w, gpu_pairs_by_step):
+    """The CPU oracle (oracle/: an OpenMP port of the reference's algorithms, kind "port") on a
+    bounded sample of the SAME workload: the first 3 supersteps of the timed region (1 untimed, 2
+    timed), from the state the GPU's timed region started from. Before the timing is accepted the
+    GPU path (a fresh simulation from that state) and the oracle must agree on every superstep:
+    outcome, broad-phase pair count, collision and conjunction lists, and the states to 1e-9."""
+    from cascade_amd import sim
     from oracle import orc_py
 
     orc_py.build()
-    n = min(args.cpu_sample, args.nparts)
-    st = random_leo_pop_kep(args.nparts, seed=42)[:n]
-    s = orc_py.Sim(st, args.ct, n_par_ct=args.n_par_ct)
-    s.step()
-    t_sim0 = s.time
-    t0 = time.perf_counter()
-    nsteps = 2
-    for _ in range(nsteps):
-        s.step()
-    wall = time.perf_counter() - t0
-    od = n * (s.time - t_sim0) * TU_SECONDS / 86400.0
+    n = len(st_w)
+    nsteps = 3
+    g = sim(st_w.copy(), args.ct, n_par_ct=args.n_par_ct)
+    g.time = t_w
+    o = orc_py.Sim(st_w.copy(), args.ct, n_par_ct=args.n_par_ct)
+    o.time = t_w
+    walls, t_sim = [], []
+    checked = []
+    for k in range(nsteps):
+        og = g.step()
+        t_sim.append(o.time)
+        t0 = time.perf_counter()
+        oo = o.step()
+        walls.append(time.perf_counter() - t0)
+        np_o = int(o.stage_times()["n_bp_pairs"])
+        assert og.name == oo, ("outcome", k, og.name, oo)
+        assert g.last_bp_pairs == np_o, ("pair count", k, g.last_bp_pairs, np_o)
+        if k < len(gpu_pairs_by_step):
+            assert gpu_pairs_by_step[k] == np_o, ("pair count of the timed region", k, gpu_pairs_by_step[k], np_o)
+        cg, co = g.last_collisions, o.collisions()
+        assert len(cg) == len(co) and np.array_equal(cg["i"], co["i"]) and np.array_equal(cg["j"], co["j"]), ("collisions", k)
+        jg, jo = g.last_step_conjunctions, o.step_conjunctions()
+        assert len(jg) == len(jo) and np.array_equal(jg["i"], jo["i"]) and np.array_equal(jg["j"], jo["j"]), ("conjunctions", k)
+        so = o.state
+        assert np.all(np.abs(g.state - so) <= 1e-9 * np.maximum(1.0, np.abs(so))), ("state", k)
+        checked.append({"outcome": oo, "bp_pairs": np_o, "collisions": len(co), "conjunctions": len(jo)})
+    wall = sum(walls[1:])
+    od = n * (o.time - t_sim[1]) * TU_SECONDS / 86400.0
     return {
         "value": round(od / wall, 2),
         "unit": "object-days/s",
         "cores": int(orc_py.lib().orc_num_threads()),
         "kind": "port",
-        "sample": "first %d objects of the same seeded population, %d steps of ct=%g x n_par_ct=%d (%.3f s of CPU wall)" % (n, nsteps, args.ct, args.n_par_ct, wall),
-        "stage_times_last_step_s": s.stage_times(),
+        "sample": "supersteps 1-3 of the timed region from the same state (%d objects, ct=%g x n_par_ct=%d): 1 untimed + 2 timed, %.3f s of CPU wall" % (n, args.ct, args.n_par_ct, wall),
+        "checked_against_gpu": checked,
+        "check": "outcome, broad-phase pair count, collision and conjunction lists equal; states within 1e-9 relative",
+        "stage_times_last_step_s": o.stage_times(),
     }
 
 

@@ -132,6 +132,8 @@ SYMBOLS = {
     "csc_narrow_phase_finish": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 7 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
     "csc_narrow_phase_candidates": (_u64, [_vp]),
     "csc_narrow_phase_attempts": (C.c_uint32, [_vp]),
+    "csc_global_aabb_noalloc": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "csc_global_aabb_noalloc_max_chunks": (C.c_uint32, []),
     "csc_narrow_phase_pairs": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 9 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
     "csc_narrow_phase_get": (_i32, [_vp, _vp, _u64, _vp, _u64]),
     "csc_dense_propagate": (_i32, [_vp, _u32, _u32, _dbl] + [_vp] * 6),

@@ -28,6 +28,13 @@
 #include "k_propagate.hpp"
 #include "k_scan_sort.hpp"
 
+// Scratch of csc_global_aabb_noalloc (the one entry point that allocates nothing): partial
+// (min, max) boxes of the block reduction. A file-scope device array: every GPU the library runs
+// on holds its own copy at its own address until the process ends. In host code the NAME is only
+// a stand-in for hipGetSymbolAddress (csc_ctx_create); kernels get the address it returned.
+constexpr size_t CSC_NA_SCRATCH_F4 = 65536; // float4 slots = 1 MiB
+static __device__ __align__(256) float4 scratch[CSC_NA_SCRATCH_F4];
+
 namespace
 {
 
@@ -46,7 +53,7 @@ struct csc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<std::string, dbuf> bufs;
-    int *d_flags = nullptr; // [0] morton non-finite box, [1] dense: no substeps, [2] broad-phase stack overflow
+    int *d_flags = nullptr; // [0] morton non-finite box, [1] dense: no substeps, [2] broad-phase stack overflow, [3] store pass != pass 1
     // BVH state of the last csc_bvh_build
     csc::bvh_bufs bvh{};
     uint32_t bvh_n = 0, bvh_chunks = 0;
@@ -95,6 +102,7 @@ struct csc_ctx {
     bool profiling = false;
     std::string profile_only; // when not empty: only this kernel is timed
     std::vector<csc_tape_op> tape_host; // the tape currently in the "tape_ops" buffer
+    float4 *na_scratch = nullptr;       // device address of `scratch` on this context's device
     void kt_begin(const char *name)
     {
         if (!profiling || (!profile_only.empty() && profile_only != name)) {
@@ -672,6 +680,13 @@ int csc_ctx_create(int device, csc_ctx **out)
     }
     // [0..1] error flags (int), broad-phase pair counter: u64 at byte offset 64.
     ctx->d_bp_counter = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->d_flags) + 64);
+    // Address of the static scratch array on THIS device (the device is current, see above).
+    if ((e = hipGetSymbolAddress(reinterpret_cast<void **>(&ctx->na_scratch), HIP_SYMBOL(scratch))) != hipSuccess
+        || ctx->na_scratch == nullptr) {
+        g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+        csc_ctx_destroy(ctx);
+        return CSC_ERR_HIP;
+    }
     *out = ctx;
     return CSC_OK;
 }
@@ -810,10 +825,10 @@ int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap)
 
 int csc_check_flags(csc_ctx *ctx)
 {
-    int h[3] = {0, 0, 0};
+    int h[4] = {0, 0, 0, 0};
     CSC_HIP(hipMemcpyAsync(h, ctx->d_flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     CSC_HIP(hipStreamSynchronize(ctx->stream));
-    if (h[0] || h[1] || h[2]) {
+    if (h[0] || h[1] || h[2] || h[3]) {
         CSC_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(h), ctx->stream));
     }
     if (h[0]) {
@@ -827,6 +842,11 @@ int csc_check_flags(csc_ctx *ctx)
     if (h[2]) {
         ctx->err = "broad phase traversal stack overflow (BVH deeper than 64 levels?)";
         return CSC_ERR_OVERFLOW;
+    }
+    if (h[3]) {
+        ctx->err = "csc_propagate_store: the second integration pass did not repeat the substep count of the first "
+                   "(the Taylor rows of the superstep are not valid)";
+        return CSC_ERR_HIP;
     }
     return CSC_OK;
 }
@@ -975,6 +995,8 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
     }
     csc::prop_params p = make_prop_params(cfg, n, d_state);
     p.order = d_order;
+    p.nsub_in = d_nsub;
+    p.store_err = ctx->d_flags + 3;
     p.row_base = d_base;
     p.tc_row = d_tc_row;
     p.tcs_xyz = d_tcs_xyz;
@@ -1065,6 +1087,42 @@ int csc_global_aabb(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_l
                        reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n, d_part));
     KT("k_gaabb_final", hipLaunchKernelGGL(csc::k_gaabb_final, dim3(nchunks), dim3(64), 0, ctx->stream, d_part, nb,
                        reinterpret_cast<float4 *>(d_glb), reinterpret_cast<float4 *>(d_gub)));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+uint32_t csc_global_aabb_noalloc_max_chunks(void)
+{
+    return static_cast<uint32_t>(CSC_NA_SCRATCH_F4 / 2u);
+}
+
+// The same two kernels as csc_global_aabb, the partial boxes in the static device array: no
+// hipMalloc / hipFree / event creation on this path. The number of partial boxes per chunk is
+// cut to what the array holds; min / max are exact, so the split does not change a bit of the
+// result. Every partial slot that stage 2 reads was written by stage 1 of the same call (nothing
+// has to start from zero); calls that overlap on one GPU (two contexts, two streams) race.
+int csc_global_aabb_noalloc(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs,
+                            float *d_glb, float *d_gub)
+{
+    if (ctx->na_scratch == nullptr) {
+        return ctx->invalid("csc_global_aabb_noalloc: the static scratch array was not resolved");
+    }
+    if (n == 0u || nchunks == 0u || !d_lbs || !d_ubs || !d_glb || !d_gub) {
+        return ctx->invalid("csc_global_aabb_noalloc: empty input");
+    }
+    const size_t max_chunks = CSC_NA_SCRATCH_F4 / 2u;
+    if (nchunks > max_chunks) {
+        ctx->err = "csc_global_aabb_noalloc: " + std::to_string(nchunks) + " chunks exceed the maximum of "
+                   + std::to_string(max_chunks) + " that the static scratch array holds";
+        return CSC_ERR_INVALID;
+    }
+    const unsigned nb = std::min<unsigned>({cdiv(n, csc::GA_BLOCK * 4), static_cast<unsigned>(csc::GA_MAX_PARTIAL),
+                                            static_cast<unsigned>(max_chunks / nchunks)});
+    float4 *d_part = ctx->na_scratch;
+    hipLaunchKernelGGL(csc::k_gaabb_partial, dim3(nb, nchunks), dim3(csc::GA_BLOCK), 0, ctx->stream,
+                       reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n, d_part);
+    hipLaunchKernelGGL(csc::k_gaabb_final, dim3(nchunks), dim3(64), 0, ctx->stream, static_cast<const float4 *>(d_part), nb,
+                       reinterpret_cast<float4 *>(d_glb), reinterpret_cast<float4 *>(d_gub));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }

@@ -11,6 +11,7 @@
 //       core.cpp -Lcascade_amd -lcascade -lcascade_hip -Wl,-rpath,'$ORIGIN' -o cascade_amd/core<ext>.so
 
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <optional>
 #include <sstream>
@@ -308,28 +309,20 @@ PYBIND11_MODULE(core, m)
         .def(
             "set_shard",
             [](sim &s, std::uint32_t rank, std::uint32_t nranks, py::object exchange) {
-                // exchange(coll, conj) -> (coll, conj): numpy record arrays in, merged arrays out.
+                // exchange(local) -> all: a numpy int64[6] in (the 48-byte summary), int64[nranks, 6] out.
+                static_assert(sizeof(sim::shard_summary) == 6 * sizeof(std::int64_t), "summary layout");
                 sim::exchange_t fn;
                 if (!exchange.is_none()) {
-                    fn = [exchange](std::vector<sim::collision_t> &coll, std::vector<sim::conjunction> &conj) {
+                    fn = [exchange](const sim::shard_summary &mine, std::vector<sim::shard_summary> &all) {
                         py::gil_scoped_acquire gil;
-                        py::array_t<coll_rec> c_in(static_cast<py::ssize_t>(coll.size()));
-                        auto *cp = static_cast<coll_rec *>(c_in.mutable_data());
-                        for (std::size_t k = 0; k < coll.size(); ++k) {
-                            cp[k] = coll_rec{std::get<0>(coll[k]), std::get<1>(coll[k]), std::get<2>(coll[k])};
+                        py::array_t<std::int64_t> in(6);
+                        std::memcpy(in.mutable_data(), &mine, sizeof(mine));
+                        const auto out = exchange(in).cast<py::array_t<std::int64_t, py::array::c_style | py::array::forcecast>>();
+                        if (out.size() % 6 != 0) {
+                            throw std::runtime_error("sharded simulation: malformed exchange result");
                         }
-                        py::array_t<sim::conjunction> j_in(static_cast<py::ssize_t>(conj.size()));
-                        std::copy(conj.begin(), conj.end(), static_cast<sim::conjunction *>(j_in.mutable_data()));
-                        const py::tuple out = exchange(c_in, j_in);
-                        const auto c_out = out[0].cast<py::array_t<coll_rec, py::array::c_style | py::array::forcecast>>();
-                        const auto j_out
-                            = out[1].cast<py::array_t<sim::conjunction, py::array::c_style | py::array::forcecast>>();
-                        coll.resize(static_cast<std::size_t>(c_out.size()));
-                        for (std::size_t k = 0; k < coll.size(); ++k) {
-                            const coll_rec &r = c_out.data()[k];
-                            coll[k] = sim::collision_t{r.i, r.j, r.time};
-                        }
-                        conj.assign(j_out.data(), j_out.data() + j_out.size());
+                        all.resize(static_cast<std::size_t>(out.size() / 6));
+                        std::memcpy(static_cast<void *>(all.data()), out.data(), all.size() * sizeof(sim::shard_summary));
                     };
                 }
                 s.set_shard(rank, nranks, std::move(fn));
@@ -349,10 +342,22 @@ PYBIND11_MODULE(core, m)
                 s.set_shard_propagation(std::move(fn));
             },
             "gather"_a = py::none{})
+        .def_property_readonly("_conj_segments",
+                               [](const sim &s) {
+                                   const auto &v = s._get_conj_segments();
+                                   py::array_t<std::uint64_t> out({static_cast<py::ssize_t>(v.size()), static_cast<py::ssize_t>(2)});
+                                   auto *p = out.mutable_data();
+                                   for (std::size_t k = 0; k < v.size(); ++k) {
+                                       p[2 * k] = v[k].first;
+                                       p[2 * k + 1] = v[k].second;
+                                   }
+                                   return out;
+                               })
         .def("upload_state", &sim::upload_state)
         .def("download_state", &sim::download_state)
         .def_property_readonly("last_bp_pairs", [](const sim &s) { return s.get_step_stats().bp_pairs; })
         .def_property_readonly("last_np_candidates", [](const sim &s) { return s.get_step_stats().np_candidates; })
+        .def_property_readonly("last_stored_objects", [](const sim &s) { return s.get_step_stats().stored_objects; })
         .def_property_readonly("last_np_attempts", [](const sim &s) { return s.get_step_stats().np_attempts; })
         .def_property_readonly("last_propagated", [](const sim &s) { return s.get_step_stats().propagated; })
         .def_property_readonly("last_bp_node_pairs", [](const sim &s) { return s.get_step_stats().bp_node_pairs; })

@@ -396,6 +396,8 @@ struct sim::sim_data {
     std::uint32_t shard_rank = 0, shard_n = 1;
     exchange_t exchange;
     gather_t gather; // propagation sharded too when set
+    std::uint64_t step_counter = 0; // step() calls so far (identical on the processes of a sharded simulation)
+    std::vector<std::pair<std::uint64_t, std::uint64_t>> conj_segments;
     step_stats stats;
     std::vector<std::tuple<size_type, size_type, double>> last_coll;
     std::vector<conjunction> last_conj;
@@ -760,6 +762,12 @@ void sim::set_conj_thresh(double v)
 void sim::reset_conjunctions()
 {
     m_det_conj = std::make_shared<std::vector<conjunction>>();
+    m_data->conj_segments.clear();
+}
+
+const std::vector<std::pair<std::uint64_t, std::uint64_t>> &sim::_get_conj_segments() const
+{
+    return m_data->conj_segments;
 }
 
 void sim::set_min_coll_radius(double v)
@@ -975,6 +983,9 @@ void sim::append_conj_data(const void *recs, std::size_t n)
     }
     const auto *src = static_cast<const conjunction *>(recs);
     m_det_conj->insert(m_det_conj->end(), src, src + n);
+    if (n) {
+        m_data->conj_segments.emplace_back(m_data->step_counter, n);
+    }
 }
 
 // dense_propagate (src/sim_propagate.cpp:1386-1503) + copy_from_final_state.
@@ -1037,6 +1048,7 @@ outcome sim::step()
     d.ensure_ctx();
     csc_ctx *ctx = d.ctx;
     phase_timer pt;
+    ++d.step_counter;
 
     if ((d.host_sync && !(d.in_loop && d.loop_uploaded)) || d.dev_rows != static_cast<std::int64_t>(nparts)) {
         // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
@@ -1241,6 +1253,7 @@ outcome sim::step()
     pt.lap("sort/bvh/bp");
     std::uint64_t ncoll = 0, nconj = 0;
     std::uint32_t warn = 0, np_attempts = 0;
+    d.stats.stored_objects = n;
     // Taylor coefficients for dense output when the integration did not write them: exact-fit CSR
     // rows, of every particle in the Morton order of chunk 0 (two-pass mode), or only of the
     // particles that the candidate pairs involve.
@@ -1250,6 +1263,7 @@ outcome sim::step()
         d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
         d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
         d.rows_full = true;
+        d.stats.stored_objects = n;
     };
     if (sparse) {
         std::uint64_t ncand = 0, nrows = 0;
@@ -1264,6 +1278,7 @@ outcome sim::step()
         if (static_cast<std::uint64_t>(nlist) * 4u > n || d.want_full_rows) {
             store_all();
         } else {
+            d.stats.stored_objects = nlist;
             d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(nrows, 1) * xs);
             d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(nrows, 1) * vs);
             d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(nrows, 1) * 2u);
@@ -1283,7 +1298,11 @@ outcome sim::step()
         d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
                                d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
     }
-    d.sparse_likely = csc_narrow_phase_candidates(ctx) * 8u <= n;
+    if (!rows_done) {
+        // A second integration pass wrote the rows: it must have repeated the substep counts of the
+        // first one (csc_propagate_store never writes past a particle's rows and reports a mismatch).
+        d.chk(csc_check_flags(ctx));
+    }
     // The event lists stay in the context (pinned host memory; a conjunction-heavy superstep
     // yields millions of 128-byte records): no copies besides the append to m_det_conj below.
     const csc_collision *coll_p = nullptr;
@@ -1307,27 +1326,39 @@ outcome sim::step()
     d.last_conj_view = conj_p;
     d.last_conj_n = nconj_v;
     std::vector<csc_collision> coll(coll_p, coll_p + ncoll_v);
-    std::vector<csc_conjunction> conj_merged; // sharded mode only
+    std::uint64_t ncand_all = csc_narrow_phase_candidates(ctx);
     if (d.shard_n > 1u) {
-        // Merge the event lists of all processes; from here on every process works on the same
-        // data (the propagation results are identical everywhere by construction).
-        d.last_conj.resize(nconj_v);
-        if (nconj_v) {
-            std::memcpy(static_cast<void *>(d.last_conj.data()), conj_p, nconj_v * sizeof(conjunction));
+        // One 48-byte summary per process: the outcome logic below needs the earliest collision
+        // of all processes (coll is sorted by (time, i, j)); the conjunction records stay here.
+        shard_summary mine;
+        mine.n_coll = ncoll_v;
+        mine.n_conj = nconj_v;
+        mine.n_cand = ncand_all;
+        if (ncoll_v) {
+            mine.coll_i = coll[0].i;
+            mine.coll_j = coll[0].j;
+            mine.coll_time = coll[0].time;
         }
-        d.last_conj_view = nullptr;
-        d.exchange(d.last_coll, d.last_conj);
-        coll.resize(d.last_coll.size());
-        for (std::size_t k = 0; k < coll.size(); ++k) {
-            coll[k] = csc_collision{std::get<0>(d.last_coll[k]), std::get<1>(d.last_coll[k]), std::get<2>(d.last_coll[k])};
+        std::vector<shard_summary> all;
+        d.exchange(mine, all);
+        if (all.size() != d.shard_n) {
+            throw std::runtime_error("sharded simulation: the exchange returned " + std::to_string(all.size())
+                                     + " summaries for " + std::to_string(d.shard_n) + " processes");
         }
-        conj_merged.resize(d.last_conj.size());
-        if (!conj_merged.empty()) {
-            std::memcpy(static_cast<void *>(conj_merged.data()), d.last_conj.data(), conj_merged.size() * sizeof(conjunction));
+        coll.clear();
+        ncand_all = 0;
+        for (const auto &s : all) {
+            ncand_all += s.n_cand;
+            if (s.n_coll) {
+                const csc_collision c{s.coll_i, s.coll_j, s.coll_time};
+                if (coll.empty() || std::tie(c.time, c.i, c.j) < std::tie(coll[0].time, coll[0].i, coll[0].j)) {
+                    coll.assign(1, c);
+                }
+            }
         }
-        conj_p = conj_merged.data();
-        nconj_v = conj_merged.size();
     }
+    // (the same decision on every process: ncand_all is the global count)
+    d.sparse_likely = ncand_all * 8u <= n;
 
     // Outcome resolution (:1189-1345). coll is sorted by (time, i, j); a collision wins a tie
     // with a terminal event (:1225).

@@ -110,6 +110,8 @@ struct prop_params {
     // first + k, k < n, and the per-chunk arrays hold n_total particles per chunk.
     std::uint32_t first, n_total;
     // pass 2
+    const std::uint32_t *nsub_in;   // [N] substeps pass 1 counted for particle i: the rows particle i owns
+    int *store_err;                 // set when pass 2 does not repeat pass 1's substep count
     const std::uint32_t *order;     // [N] particle handled by lane k (null = identity)
     const std::uint64_t *row_base;  // [N] first CSR row of lane k
     std::uint64_t *tc_row;          // [N] out: first CSR row of particle i
@@ -753,9 +755,11 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
     };
 
     std::size_t row = 0;
+    std::uint32_t ns_owned = 0; // pass 2: the rows [row, row + ns_owned) belong to this particle
     if constexpr (STORE) {
         row = prm.row_base[lane_k];
         prm.tc_row[i] = row;
+        ns_owned = prm.nsub_in[i];
     } else {
         if (prm.row_cap != 0u) {
             row = static_cast<std::size_t>(i) * prm.row_cap;
@@ -885,7 +889,11 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                 flags |= ST_FLAG_BAD_TCOORD;
             }
             if constexpr (STORE) {
-                write_row(row + ns, tc);
+                // Never beyond the rows pass 1 counted for this particle (they are followed by the
+                // next particle's): a pass that disagrees with pass 1 is reported below.
+                if (ns < ns_owned) {
+                    write_row(row + ns, tc);
+                }
             }
             if constexpr (!STORE) {
                 if (prm.row_cap != 0u) {
@@ -998,6 +1006,11 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
         }
     }
 
+    if constexpr (STORE) {
+        if (ns != ns_owned) {
+            atomicOr(prm.store_err, 1);
+        }
+    }
     if constexpr (!STORE) {
         flush_box();
         prm.nsub[i] = ns;

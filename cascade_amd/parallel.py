@@ -1,61 +1,42 @@
-"""Multi-GPU operation of ``cascade_amd.sim``: one process per GPU, ``torch.distributed``.
+"""Multi-GPU operation of ``cascade_amd.sim``: one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
 
-Every process holds the same simulation. The broad and narrow phases are sharded over the pair
-tree (``csc_set_shard``), and the per-step lists of detected collisions and conjunctions are merged
-with one small all-gather (``make_event_exchange``; a second one only when some process found an
-event). By default propagation, sort and tree build run redundantly on each GPU (at 1M Kepler
-objects they take ~2 ms, less than moving the per-particle results over xGMI would);
-``shard(sim, propagation=True)`` shards the integration as well: every process integrates its own
-range of particles and ONE all-gather of 80 + 96 C bytes per particle (``make_device_gather``,
-in place on the simulation's device buffers) gives everybody the boxes, trajectory records, substep
-counts and final states -- worth it when the integration dominates the superstep (DESIGN.md
-section 7). Backend "nccl" (RCCL over xGMI) on GPUs, "gloo" in the tests.
+Every process holds the same simulation (same state, same calls). Per superstep
+(``shard(sim)``, the partition BASELINE.json's north_star names):
+
+  1. each process integrates ITS range of particles (``csc_propagate_range``);
+  2. ONE all-gather of the per-particle records -- substep count, status, event, final state and,
+     per chunk, the box and the 64-byte trajectory record: 80 + 96 C bytes -- in place on the
+     simulation's device buffers (``make_device_gather``);
+  3. every process sorts the Morton codes and builds the whole tree (replicated: cheaper than a
+     distributed sort at these sizes, and it makes the tree bit-identical everywhere), expands
+     only its share of the pair tree and runs the narrow phase on the pairs it found; Taylor rows
+     are produced on demand for the particles of its candidate pairs;
+  4. ONE all-gather of a 48-byte summary per process (``make_summary_exchange``: event counts
+     and the earliest local collision), from which every process derives the same outcome.
+
+Conjunction records never travel during the run: ``sim.conjunctions`` holds the records found by
+this process; ``gather_conjunctions(sim)`` merges them into the list the unsharded simulation
+would hold. ``shard(sim, propagation=False)`` keeps the integration on every process (no step 2).
 """
 import numpy as np
 
 
-def merge_events(parts_coll, parts_conj):
-    """Concatenate per-process event arrays and sort them by (time, i, j): the container order
-    the single-process narrow phase produces (libcascade_hip sorts its lists the same way)."""
-    coll = np.concatenate(parts_coll) if parts_coll else np.empty(0)
-    conj = np.concatenate(parts_conj) if parts_conj else np.empty(0)
-    if len(coll) > 1:
-        coll = coll[np.lexsort((coll["j"], coll["i"], coll["time"]))]
-    if len(conj) > 1:
-        conj = conj[np.lexsort((conj["j"], conj["i"], conj["time"]))]
-    return coll, conj
-
-
-def make_event_exchange(group=None, device=None):
-    """exchange(coll, conj) -> (coll, conj) over the processes of ``group``."""
+def make_summary_exchange(group=None, device=None):
+    """exchange(local int64[6]) -> int64[world, 6]: one all-gather on a device tensor (RCCL) --
+    or on a host tensor with the gloo backend."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    recv = torch.empty(world * 6, dtype=torch.int64, device=device)  # flat: what gloo accepts too
 
-    def exchange(coll, conj):
-        counts = torch.tensor([coll.nbytes, conj.nbytes], dtype=torch.int64, device=device)
-        all_counts = torch.empty(world * 2, dtype=torch.int64, device=device)  # flat: what gloo accepts too
-        dist.all_gather_into_tensor(all_counts, counts, group=group)
-        all_counts = all_counts.cpu().numpy().reshape(world, 2)
-        if not all_counts.any():
-            return coll, conj
-        nmax = int(all_counts.sum(axis=1).max())
-        payload = np.zeros(nmax, dtype=np.uint8)
-        payload[: coll.nbytes] = coll.view(np.uint8).reshape(-1)
-        payload[coll.nbytes : coll.nbytes + conj.nbytes] = conj.view(np.uint8).reshape(-1)
-        send = torch.from_numpy(payload).to(device)
-        recv = torch.empty(world * nmax, dtype=torch.uint8, device=device)
+    def exchange(local):
+        send = torch.from_numpy(np.ascontiguousarray(local, dtype=np.int64)).to(device)
         dist.all_gather_into_tensor(recv, send, group=group)
-        recv = recv.cpu().numpy().reshape(world, nmax)
-        pc, pj = [], []
-        for r in range(world):
-            nc, nj = int(all_counts[r, 0]), int(all_counts[r, 1])
-            pc.append(recv[r, :nc].copy().view(coll.dtype))
-            pj.append(recv[r, nc : nc + nj].copy().view(conj.dtype))
-        return merge_events(pc, pj)
+        return recv.cpu().numpy().reshape(world, 6)
 
     return exchange
 
@@ -92,15 +73,49 @@ def make_device_gather(group=None):
     return gather
 
 
-def shard(sim_obj, group=None, propagation=False):
+def shard(sim_obj, group=None, propagation=True):
     """Shard ``sim_obj`` over the processes of ``group`` (call it on every process, on
-    simulations constructed from the same arguments). ``propagation=True`` shards the
-    integration too (one all-gather of 80 + 96 C bytes per particle and superstep): worth it when
-    the integration dominates the superstep, see DESIGN.md section 7."""
+    simulations constructed from the same arguments). ``propagation=False`` keeps the integration
+    replicated on every process (no all-gather of the per-particle records)."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if world > 1:
-        sim_obj.set_shard(rank, world, make_event_exchange(group))
+        sim_obj.set_shard(rank, world, make_summary_exchange(group))
         sim_obj.set_shard_propagation(make_device_gather(group) if propagation else None)
     return sim_obj
+
+
+def merge_conjunctions(parts):
+    """parts: per process, (records, segments) as ``sim.conjunctions`` / ``sim._conj_segments``
+    give them. Returns the list of the unsharded simulation: superstep by superstep, the records
+    of each sorted by (time, i, j) (the container order of the single-process narrow phase)."""
+    chunks = []
+    for recs, segs in parts:
+        off = 0
+        for step, cnt in np.asarray(segs, dtype=np.uint64).reshape(-1, 2):
+            chunks.append((int(step), recs[off : off + int(cnt)]))
+            off += int(cnt)
+        assert off == len(recs), "conjunction segments do not cover the records"
+    if not chunks:
+        return parts[0][0][:0].copy()
+    out = []
+    for step in sorted({c[0] for c in chunks}):
+        c = np.concatenate([r for s, r in chunks if s == step])
+        out.append(c[np.lexsort((c["j"], c["i"], c["time"]))])
+    return np.concatenate(out)
+
+
+def gather_conjunctions(sim_obj, group=None):
+    """The conjunctions of a sharded simulation as the unsharded one would hold them (collective:
+    call it on every process; host-side object gather, meant for the end of a run, not for the
+    superstep loop)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    mine = (np.array(sim_obj.conjunctions), np.array(sim_obj._conj_segments))
+    if world == 1:
+        return merge_conjunctions([mine])
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    return merge_conjunctions(parts)

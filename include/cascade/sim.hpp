@@ -212,6 +212,7 @@ public:
         std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles
         std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)
+        std::uint64_t stored_objects = 0; // particles whose Taylor rows were written (all, or those of the candidate pairs)
         std::uint32_t np_attempts = 0;    // narrow-phase passes (more than one per call: an output list overflowed and was grown)
     };
 
@@ -374,17 +375,28 @@ public:
     void upload_state();
     void download_state();
     // Multi-GPU operation (no counterpart in the reference, which is single-process): `nranks`
-    // processes, one per GPU, hold the SAME simulation (same state, same calls). Each propagates
-    // every particle and builds the whole tree (cheaper than moving the boxes over xGMI at these
-    // sizes), walks it only for its share of the query particles and runs the narrow phase on
-    // the pairs it found; `exchange` then merges the per-process collision and conjunction lists
-    // (it receives the local lists, both sorted by (time, i, j), and must return the merged
-    // lists in the same order, identical on every process -- see cascade_amd/parallel.py for
-    // the torch.distributed implementation), after which every process applies the reference's
-    // outcome logic to the same data and stays in lockstep.
+    // processes, one per GPU, hold the SAME simulation (same state, same calls). Every process
+    // sorts and builds the whole tree, expands only its share of the pair tree and runs the narrow
+    // phase on the pairs it found. What the outcome logic (src/sim_propagate.cpp:1189-1345) needs
+    // from the others is small: whether anybody found a collision and which one is the earliest.
+    // `exchange(local, all)` all-gathers one 48-byte summary per process (all[r] = summary of rank
+    // r, identical on every process; cascade_amd/parallel.py does it with one RCCL all-gather on
+    // device tensors), after which every process applies the reference's outcome logic to the
+    // same data and stays in lockstep. Conjunction records stay on the process that found them:
+    // get_conjunctions() holds the local ones (cascade_amd.parallel.gather_conjunctions merges
+    // them into the unsharded list when the caller wants it), and get_last_collisions() the local
+    // collisions of the last step.
     using collision_t = std::tuple<size_type, size_type, double>;
-    using exchange_t = std::function<void(std::vector<collision_t> &, std::vector<conjunction> &)>;
+    struct shard_summary {
+        std::uint64_t n_coll = 0, n_conj = 0, n_cand = 0; // local collisions, conjunctions, narrow-phase candidates
+        std::uint64_t coll_i = 0, coll_j = 0;             // earliest local collision (when n_coll != 0)
+        double coll_time = 0;                             // relative to the superstep start
+    };
+    using exchange_t = std::function<void(const shard_summary &, std::vector<shard_summary> &)>;
     void set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchange);
+    // Bookkeeping for merging the per-process conjunction lists: (superstep counter, records
+    // appended by it) for every step() that appended records since the last reset_conjunctions().
+    [[nodiscard]] const std::vector<std::pair<std::uint64_t, std::uint64_t>> &_get_conj_segments() const;
     // Propagation sharded too (the north star's exchange: every process integrates the particles
     // [rank * m, (rank + 1) * m), m = ceil(N / nranks), and the per-particle results -- substep
     // counts, events, final states, per-chunk boxes and trajectory records, 80 + 96 C bytes each --

@@ -240,6 +240,18 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
 int csc_global_aabb(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs, float *d_glb,
                     float *d_gub);
 
+/* The ONE entry point that allocates nothing (no counterpart in the reference; for callers that
+ * cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation). Same result, bit for bit, as csc_global_aabb; the partial boxes of the reduction
+ * live in a static device array of 1 MiB (file scope of the library, one copy per GPU, resolved by
+ * csc_ctx_create), so it calls no hipMalloc / hipFree / event creation. Limits: nchunks <=
+ * csc_global_aabb_noalloc_max_chunks() (32768), otherwise CSC_ERR_INVALID with a message; n >= 1.
+ * All contexts on one GPU share that array: calls that overlap on one GPU race. Asynchronous on the
+ * context's stream; not timed by csc_profile_*. */
+int csc_global_aabb_noalloc(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs,
+                            float *d_glb, float *d_gub);
+uint32_t csc_global_aabb_noalloc_max_chunks(void);
+
 /* ---- K3/K4: Morton codes, sort, gather -------------------------------------------------
  * csc_morton_encode: src/sim_propagate.cpp:440-479 (+ disc_single_coord :94-124 and
  * MortonNDLutEncoder<4,16,8>, src/detail/mortonND_LUT.h:166-323). The ulp bump of the global

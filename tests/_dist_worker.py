@@ -15,42 +15,74 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     mode = sys.argv[1]
-    dist.init_process_group(backend="gloo")
+    # CSC_TEST_BACKEND=nccl (RCCL): one GPU per rank; gloo (default): all ranks on cuda:0.
+    backend = os.environ.get("CSC_TEST_BACKEND", "gloo")
+    dev = 0
+    if backend == "nccl":
+        import torch
+
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+    dist.init_process_group(backend=backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     from cascade_amd import _capi
-    from cascade_amd.parallel import make_event_exchange, merge_events
 
     if mode == "exchange":
-        ex = make_event_exchange()
+        from cascade_amd.parallel import make_summary_exchange, merge_conjunctions
+
+        ex = make_summary_exchange()
+        for step in range(3 if backend == "gloo" else 0):
+            local = np.array([rank * 3 + step, 7 - rank, 100 + rank, rank, rank + 10, 0], dtype=np.int64)
+            local[5:6].view(np.float64)[0] = 0.25 * (rank + 1) + step
+            out = ex(local)
+            assert out.shape == (world, 6)
+            for r in range(world):
+                assert out[r, 0] == r * 3 + step and out[r, 3] == r and out[r, 5:6].view(np.float64)[0] == 0.25 * (r + 1) + step
+        # Merging rank-local conjunction lists: segments of the same superstep are merged by
+        # (time, i, j), supersteps stay in order even when their time ranges overlap (the last
+        # superstep of a propagate_until keeps records beyond the final time).
         rng = np.random.default_rng(100 + rank)
-        # Step 1: nobody has events. Step 2: ragged lists (rank 0 empty). Step 3: ties in time.
-        for step, (nc, nj) in enumerate([(0, 0), (3 * rank, 2 * rank + (rank == 1)), (2, 1)]):
-            coll = np.zeros(nc, dtype=_capi.COLL_DTYPE)
-            conj = np.zeros(nj, dtype=_capi.CONJ_DTYPE)
-            coll["i"], coll["j"] = rng.integers(0, 50, nc), rng.integers(50, 100, nc)
-            coll["time"] = rng.random(nc) if step < 2 else 0.5
-            conj["i"], conj["j"] = rng.integers(0, 50, nj), rng.integers(50, 100, nj)
-            conj["time"], conj["dist"] = rng.random(nj), rng.random(nj)
-            conj["state_i"] = rng.random((nj, 6))
-            mc, mj = ex(coll, conj)
-            # Reference result: gather the raw lists with the object collective and merge.
-            objs = [None] * world
-            dist.all_gather_object(objs, (coll, conj))
-            rc, rj = merge_events([o[0] for o in objs], [o[1] for o in objs])
-            assert mc.tobytes() == rc.tobytes() and mj.tobytes() == rj.tobytes(), (step, rank)
-            assert np.all(np.diff(mc["time"]) >= 0) and np.all(np.diff(mj["time"]) >= 0)
-            assert len(mc) == sum(len(o[0]) for o in objs) and len(mj) == sum(len(o[1]) for o in objs)
+        recs, segs = [], []
+        for step, (t0, cnt) in enumerate([(0.0, 3 + rank), (1.0, 0 if rank == 0 else 2), (0.9, 4)]):
+            c = np.zeros(cnt, dtype=_capi.CONJ_DTYPE)
+            c["i"], c["j"] = rng.integers(0, 50, cnt), rng.integers(50, 100, cnt)
+            c["time"] = np.sort(t0 + rng.random(cnt))
+            if step == 2:
+                c["time"][:2] = 1.5  # ties in time across the processes
+            recs.append(c)
+            if cnt:
+                segs.append((step + 1, cnt))
+        mine = (np.concatenate(recs), np.array(segs, dtype=np.uint64).reshape(-1, 2))
+        objs = [None] * world
+        dist.all_gather_object(objs, mine)
+        merged = merge_conjunctions(objs)
+        assert len(merged) == sum(len(o[0]) for o in objs)
+        # step-major, then (time, i, j)
+        off = 0
+        for st in (1, 2, 3):
+            cnt = sum(int(c) for o in objs for s, c in o[1] if int(s) == st)
+            part = merged[off : off + cnt]
+            key = list(zip(part["time"].tolist(), part["i"].tolist(), part["j"].tolist()))
+            assert key == sorted(key), (st, rank)
+            off += cnt
+        assert off == len(merged)
         print("exchange ok", rank)
     elif mode == "sim":
         from cascade_amd import sim
-        from cascade_amd.parallel import shard
+        from cascade_amd.parallel import gather_conjunctions, shard
         from cascade_amd.workloads import random_leo_pop_kep
+
+        def all_collisions(p):
+            objs = [None] * world
+            dist.all_gather_object(objs, np.array(p.last_collisions))
+            c = np.concatenate(objs)
+            return c[np.lexsort((c["j"], c["i"], c["time"]))]
 
         for n, n_par_ct, conj_thresh, scale in [(20000, 1, 0.0, 1.0), (6000, 3, 1e-3, 3e4)]:
             st = random_leo_pop_kep(n, seed=21)
             st[:, 6] *= scale
-            full = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj_thresh)
-            part = shard(sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj_thresh))
+            full = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj_thresh, device=dev)
+            part = shard(sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=conj_thresh, device=dev), propagation=False)
             import torch
 
             events = 0
@@ -60,13 +92,15 @@ def main():
                 assert np.array_equal(full.state, part.state)
                 assert full.time == part.time
                 # The shards partition the pair set.
-                t = torch.tensor([part.last_bp_pairs], dtype=torch.int64)
+                t = torch.tensor([part.last_bp_pairs], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
                 dist.all_reduce(t)
                 assert int(t.item()) == full.last_bp_pairs, (int(t.item()), full.last_bp_pairs)
                 assert part.last_bp_pairs < full.last_bp_pairs or full.last_bp_pairs < 100
-                assert part.last_collisions.tobytes() == full.last_collisions.tobytes()
+                assert all_collisions(part).tobytes() == full.last_collisions.tobytes()
                 events += len(full.last_collisions) + len(full.last_step_conjunctions)
-            assert part.conjunctions.tobytes() == full.conjunctions.tobytes()
+            assert gather_conjunctions(part).tobytes() == full.conjunctions.tobytes()
+            if len(full.conjunctions) > 10:
+                assert len(part.conjunctions) < len(full.conjunctions), "conjunction records stay on the rank that found them"
             if scale > 1:
                 assert events > 0
         print("sim ok", rank)
@@ -77,25 +111,32 @@ def main():
         # with reentries and removals; ragged ranges (the particle counts are no multiples of the
         # number of processes).
         from cascade_amd import dynamics, outcome, sim
-        from cascade_amd.parallel import shard
+        from cascade_amd.parallel import gather_conjunctions, shard
         from cascade_amd.workloads import leo_si_population, random_leo_pop_kep
+
+        def all_collisions(p):
+            objs = [None] * world
+            dist.all_gather_object(objs, np.array(p.last_collisions))
+            c = np.concatenate(objs)
+            return c[np.lexsort((c["j"], c["i"], c["time"]))]
 
         st = random_leo_pop_kep(6001, seed=21)
         st[:, 6] *= 3e4
-        full = sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=1e-3)
-        part = shard(sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=1e-3), propagation=True)
+        full = sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=1e-3, device=dev)
+        part = shard(sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=1e-3, device=dev), propagation=True)
         events = 0
         for _ in range(4):
             of, op = full.step(), part.step()
             assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
             assert np.array_equal(full.state, part.state)
             assert full.time == part.time
-            assert part.last_collisions.tobytes() == full.last_collisions.tobytes()
-            assert full.last_propagated == 6001 and part.last_propagated == (2001 if rank < 2 else 1999)
+            assert all_collisions(part).tobytes() == full.last_collisions.tobytes()
+            per = -(-6001 // world)
+            assert full.last_propagated == 6001 and part.last_propagated == min(per, 6001 - rank * per)
             events += len(full.last_collisions) + len(full.last_step_conjunctions)
         of, op = full.propagate_until(full.time + 1.0), part.propagate_until(part.time + 1.0)
         assert of == op and full.time == part.time and np.array_equal(full.state, part.state)
-        assert part.conjunctions.tobytes() == full.conjunctions.tobytes()
+        assert gather_conjunctions(part).tobytes() == full.conjunctions.tobytes()
         assert events > 0
 
         Re, GM = 6378136.3, 3.986004407799724e14
@@ -106,7 +147,7 @@ def main():
             v = np.sqrt(GM / r0)
             st[i, :6] = [r0 * np.cos(ang), r0 * np.sin(ang), 0.0, -v * np.sin(ang), v * np.cos(ang), 0.0]
             pars[i, 0] = 5e-2
-        kw = dict(dyn=dynamics.simple_earth(C22S22=False), n_par_ct=8, reentry_radius=Re + 150e3)
+        kw = dict(dyn=dynamics.simple_earth(C22S22=False), n_par_ct=8, reentry_radius=Re + 150e3, device=dev)
         full = sim(st.copy(), 185.5663, pars=pars.copy(), **kw)
         part = shard(sim(st.copy(), 185.5663, pars=pars.copy(), **kw), propagation=True)
         nre = 0
@@ -114,7 +155,7 @@ def main():
             of, op = full.step(), part.step()
             assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
             assert np.array_equal(full.state, part.state) and full.time == part.time
-            assert part.last_propagated <= (part.nparts + 2) // 3
+            assert part.last_propagated <= -(-part.nparts // world)
             if of == outcome.reentry:
                 nre += 1
                 full.remove_particles([full.interrupt_info])
@@ -123,14 +164,14 @@ def main():
 
         # Tape dynamics (the reference's default simple_earth: J2 + C22S22 + drag) over a range.
         st, pars = leo_si_population(301, seed=9)
-        kw = dict(dyn=dynamics.simple_earth(), n_par_ct=4, reentry_radius=Re + 150e3)
+        kw = dict(dyn=dynamics.simple_earth(), n_par_ct=4, reentry_radius=Re + 150e3, device=dev)
         full = sim(st.copy(), 185.5663, pars=pars.copy(), **kw)
         part = shard(sim(st.copy(), 185.5663, pars=pars.copy(), **kw), propagation=True)
         for _ in range(3):
             of, op = full.step(), part.step()
             assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
             assert np.array_equal(full.state, part.state) and full.time == part.time
-            assert part.last_propagated <= 101
+            assert part.last_propagated <= -(-301 // world)
         print("simprop ok", rank)
     dist.barrier()
     dist.destroy_process_group()

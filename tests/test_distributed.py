@@ -16,11 +16,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world(mode, world=2, timeout=240):
+def _run_world(mode, world=2, timeout=240, backend="gloo"):
     port = _free_port()
     procs = []
     for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CSC_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
@@ -37,7 +37,8 @@ def _run_world(mode, world=2, timeout=240):
 
 
 def test_event_exchange_gloo():
-    """The per-superstep event merge across processes: empty, ragged and tied lists."""
+    """The per-superstep summary all-gather, and the merge of rank-local conjunction lists
+    (ragged, empty, tied in time, overlapping time ranges of successive supersteps)."""
     _run_world("exchange")
 
 
@@ -55,3 +56,20 @@ def test_sharded_propagation_matches_unsharded():
     of the all-gather): same outcomes, states, event lists as the unsharded simulation, for plain
     Kepler with collisions / conjunctions and for J2 + drag with reentries and removals."""
     _run_world("simprop", world=3)
+
+
+def _gpus():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+def test_sharded_sim_rccl():
+    """The production backend: one GPU per rank, RCCL all-gathers on device tensors. Needs at
+    least two GPUs; skipped on a one-GPU box (where the gloo tests above cover the logic)."""
+    if _gpus() < 2:
+        pytest.skip("needs >= 2 GPUs: backend nccl (RCCL) with one GPU per rank")
+    world = min(_gpus(), 3)
+    _run_world("sim", world=world, backend="nccl")
+    _run_world("simprop", world=world, backend="nccl")
