@@ -27,6 +27,7 @@
 #include "k_narrow.hpp"
 #include "k_propagate.hpp"
 #include "k_scan_sort.hpp"
+#include "order_api.hpp"
 
 // Scratch of csc_global_aabb_noalloc (the one entry point that allocates nothing): partial
 // (min, max) boxes of the block reduction. A file-scope device array: every GPU the library runs
@@ -34,6 +35,24 @@
 // a stand-in for hipGetSymbolAddress (csc_ctx_create); kernels get the address it returned.
 constexpr size_t CSC_NA_SCRATCH_F4 = 65536; // float4 slots = 1 MiB
 static __device__ __align__(256) float4 scratch[CSC_NA_SCRATCH_F4];
+
+// Taylor orders other than 20: one translation unit each (cascade_order.hip, order_api.hpp).
+#define CSC_FOR_EACH_ORDER(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(21) X(22) X(23) X(24)
+#define CSC_DECLARE_ORDER(p) extern "C" const csc::order_api *csc_order_api_##p();
+CSC_FOR_EACH_ORDER(CSC_DECLARE_ORDER)
+#undef CSC_DECLARE_ORDER
+extern "C" __attribute__((visibility("hidden"))) const csc::order_api *csc_order_api(int order)
+{
+    switch (order) {
+#define CSC_ORDER_CASE(p)                                                                                              \
+    case p:                                                                                                            \
+        return csc_order_api_##p();
+        CSC_FOR_EACH_ORDER(CSC_ORDER_CASE)
+#undef CSC_ORDER_CASE
+        default:
+            return nullptr;
+    }
+}
 
 namespace
 {
@@ -545,8 +564,13 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
 }
 
 template <bool STORE>
-void launch_propagate(int dyn, bool events, dim3 grid, dim3 block, hipStream_t stream, const csc::prop_params &p)
+void launch_propagate(uint32_t order, int dyn, bool events, dim3 grid, dim3 block, hipStream_t stream, const csc::prop_params &p)
 {
+    if (order != 20u) {
+        // check_cfg has made sure that the order is built and that the dynamics come as a tape.
+        csc_order_api(static_cast<int>(order))->propagate(STORE, events, grid, block, stream, p);
+        return;
+    }
 #define CSC_PROP_CASE(D)                                                                                               \
     if (events) {                                                                                                      \
         hipLaunchKernelGGL((csc::k_propagate<20, true, STORE, D>), grid, block, 0, stream, p);                         \
@@ -576,8 +600,15 @@ int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
         return ctx->invalid("null configuration");
     }
     if (cfg->order != 20u) {
-        ctx->err = "only Taylor order 20 (tol = DBL_EPSILON) is built";
-        return CSC_ERR_UNSUPPORTED;
+        if (csc_order_api(static_cast<int>(cfg->order)) == nullptr) {
+            ctx->err = "Taylor order " + std::to_string(cfg->order) + " is not built (built: " + std::to_string(csc::ORDER_MIN)
+                       + " to " + std::to_string(csc::ORDER_MAX) + ")";
+            return CSC_ERR_UNSUPPORTED;
+        }
+        if (cfg->dyn_kind != CSC_DYN_TAPE) {
+            ctx->err = "Taylor orders other than 20 run from the dynamics tape (CSC_DYN_TAPE)";
+            return CSC_ERR_UNSUPPORTED;
+        }
     }
     if (cfg->dyn_kind != CSC_DYN_KEPLER && cfg->dyn_kind != CSC_DYN_J2 && cfg->dyn_kind != (CSC_DYN_J2 | CSC_DYN_DRAG)
         && cfg->dyn_kind != CSC_DYN_TAPE) {
@@ -637,7 +668,7 @@ static int bind_tape(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, csc::pro
     // At most 8 waves per CU resident (256 CUs): more would only add workspace.
     const uint32_t ngroups = cdiv(n, 64);
     grid = dim3(std::min<uint32_t>(ngroups, 2048u));
-    const size_t per_wave = static_cast<size_t>(cfg->tape_nslots) * 21u * 64u;
+    const size_t per_wave = static_cast<size_t>(cfg->tape_nslots) * (cfg->order + 1u) * 64u;
     CSC_BUF(d_ws, double, "tape_ws", per_wave * grid.x);
     p.tape = d_tape;
     p.tape_nops = cfg->tape_nops;
@@ -899,7 +930,7 @@ static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, con
             return rc;
         }
     }
-    KT(row_cap ? "k_propagate_rows" : "k_propagate", launch_propagate<false>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
+    KT(row_cap ? "k_propagate_rows" : "k_propagate", launch_propagate<false>(cfg->order, cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -1009,7 +1040,7 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
             return rc;
         }
     }
-    KT("k_propagate_store", launch_propagate<true>(cfg->dyn_kind, events, grid, block, ctx->stream, p));
+    KT("k_propagate_store", launch_propagate<true>(cfg->order, cfg->dyn_kind, events, grid, block, ctx->stream, p));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -1698,8 +1729,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                        const double *d_tcs_vr, const double *d_tcoords, const np_source &src, uint64_t *n_coll,
                        uint64_t *n_conj, uint32_t *warn_flags, bool prefilter_only = false)
 {
-    if (order != 20u) {
-        ctx->err = "only Taylor order 20 is built";
+    const csc::order_api *oapi = order == 20u ? nullptr : csc_order_api(static_cast<int>(order));
+    if (order != 20u && oapi == nullptr) {
+        ctx->err = "Taylor order " + std::to_string(order) + " is not built";
         return CSC_ERR_UNSUPPORTED;
     }
     ctx->coll.clear();
@@ -1831,9 +1863,15 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             cand_cap = std::max(cand_cap, h[5] + h[5] / 4u + 16u);
             continue;
         }
-        KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(cdiv(cand_cap, 64)), dim3(64), 0, ctx->stream, q));
-        KT("k_np_fex_tr", hipLaunchKernelGGL((csc::k_np_fex_tr<20>), dim3(cdiv(defer_cap, 64)), dim3(64), 0, ctx->stream, q));
-        KT("k_np_roots", hipLaunchKernelGGL((csc::k_np_roots<20>), dim3(cdiv(surv_cap, 64)), dim3(64), 0, ctx->stream, q));
+        if (oapi == nullptr) {
+            KT("k_np_fex", hipLaunchKernelGGL((csc::k_np_fex<20>), dim3(cdiv(cand_cap, 64)), dim3(64), 0, ctx->stream, q));
+            KT("k_np_fex_tr", hipLaunchKernelGGL((csc::k_np_fex_tr<20>), dim3(cdiv(defer_cap, 64)), dim3(64), 0, ctx->stream, q));
+            KT("k_np_roots", hipLaunchKernelGGL((csc::k_np_roots<20>), dim3(cdiv(surv_cap, 64)), dim3(64), 0, ctx->stream, q));
+        } else {
+            KT("k_np_fex", oapi->np_fex(dim3(cdiv(cand_cap, 64)), ctx->stream, q));
+            KT("k_np_fex_tr", oapi->np_fex_tr(dim3(cdiv(defer_cap, 64)), ctx->stream, q));
+            KT("k_np_roots", oapi->np_roots(dim3(cdiv(surv_cap, 64)), ctx->stream, q));
+        }
         CSC_LAUNCH_CHECK();
         CSC_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
@@ -2135,8 +2173,15 @@ int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, cons
                         double *d_out)
 {
     if (order != 20u) {
-        ctx->err = "only Taylor order 20 is built";
-        return CSC_ERR_UNSUPPORTED;
+        const csc::order_api *oapi = csc_order_api(static_cast<int>(order));
+        if (oapi == nullptr) {
+            ctx->err = "Taylor order " + std::to_string(order) + " is not built";
+            return CSC_ERR_UNSUPPORTED;
+        }
+        KT("k_dense", oapi->dense(dim3(cdiv(n, 256)), ctx->stream, n, t, d_tc_row, d_nsub, d_tcs_xyz, d_tcs_vr, d_tcoords, d_out,
+                                  ctx->d_flags + 1));
+        CSC_LAUNCH_CHECK();
+        return CSC_OK;
     }
     KT("k_dense", hipLaunchKernelGGL((csc::k_dense<20>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, t, d_tc_row, d_nsub,
                        d_tcs_xyz, d_tcs_vr, d_tcoords, d_out, ctx->d_flags + 1));

@@ -14,6 +14,16 @@
 //   src/sim_jit.cpp:64-113, 118-218, 234-244       pta / ssdiff3 / fex_check / rtscc / pt1
 #pragma once
 
+// Kernels that are not templates are defined once, in the main translation unit; the per-order
+// translation units (cascade_order.hip, -DCSC_ORDER=P) see the same headers and give them
+// internal linkage (unused there, dropped by the compiler).
+#ifdef CSC_ORDER
+#define CSC_GLOBAL static __global__
+#else
+#define CSC_GLOBAL __global__
+#endif
+
+
 #include <hip/hip_runtime.h>
 
 #include <cfloat>

@@ -609,6 +609,16 @@ void sim::finalise_ctor(options o)
     }
     m_data->tol = tol;
     m_data->order = order_from_tol(tol);
+    // The kernels are built for Taylor orders 6..24 (tol from ~5e-5 down to below machine epsilon;
+    // src/sim_basic.cpp:553-577 hands any tol to heyoka). Order 20 -- the default tol = epsilon --
+    // runs the hand-unrolled built-in dynamics; every other order runs from the dynamics tape.
+    if (m_data->order < 6u || m_data->order > 24u) {
+        throw std::invalid_argument("The tolerance " + fmt_d(tol) + " needs Taylor order " + std::to_string(m_data->order)
+                                    + ", and the kernels are built for orders 6 to 24");
+    }
+    if (m_data->order != 20u && m_data->dyn.kind != dynamics::dyn_t::tape) {
+        m_data->tape = lower_dynamics(m_data->dyn.eqs);
+    }
     m_data->high_accuracy = o.high_accuracy;
     m_data->compact_mode = o.compact_mode;
     m_data->device = o.device;
@@ -1041,10 +1051,6 @@ outcome sim::step()
     if (!std::isfinite(delta_t0) || delta_t0 <= 0) {
         throw std::invalid_argument("An invalid superstep size of " + fmt_d(delta_t0) + " was inferred");
     }
-    if (d.order != 20u) {
-        throw std::invalid_argument("Only tol = machine epsilon (Taylor order 20) is built into the HIP kernels, tol = "
-                                    + fmt_d(d.tol) + " needs order " + std::to_string(d.order));
-    }
     d.ensure_ctx();
     csc_ctx *ctx = d.ctx;
     phase_timer pt;
@@ -1097,7 +1103,8 @@ outcome sim::step()
     double *d_pars = m_npars != 0u ? d.buf<double>("pars", static_cast<std::size_t>(n) * m_npars) : nullptr;
 
     csc_prop_cfg cfg{};
-    cfg.dyn_kind = d.dyn.kind;
+    const bool from_tape = d.dyn.kind == dynamics::dyn_t::tape || d.order != 20u;
+    cfg.dyn_kind = from_tape ? static_cast<int>(dynamics::dyn_t::tape) : d.dyn.kind;
     cfg.order = d.order;
     cfg.mu = d.dyn.mu;
     cfg.J2 = d.dyn.J2;
@@ -1109,7 +1116,7 @@ outcome sim::step()
     }
     cfg.d_pars = d_pars;
     cfg.npars = m_npars;
-    if (d.dyn.kind == dynamics::dyn_t::tape) {
+    if (from_tape) {
         static_assert(sizeof(tape_op) == sizeof(csc_tape_op), "tape layout");
         cfg.tape = reinterpret_cast<const csc_tape_op *>(d.tape.ops.data());
         cfg.tape_nops = static_cast<std::uint32_t>(d.tape.ops.size());
@@ -1155,10 +1162,10 @@ outcome sim::step()
     // one all-gather; the rows are produced on demand whatever the dynamics.
     const bool shard_prop = d.shard_n > 1u && static_cast<bool>(d.gather) && d.np_prefilter;
     const bool sparse = shard_prop
-                        || (d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && d.sparse_likely
+                        || (d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && !from_tape && d.sparse_likely
                             && !d.want_full_rows);
     std::uint32_t row_cap = 0;
-    if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler)
+    if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler || from_tape)
         && d.row_hint != 0u) {
         row_cap = d.row_hint + std::max(2u, d.row_hint / 4u);
         if (static_cast<double>(n) * row_cap * (xs + vs + 2u) * 8. > 96e9) {

@@ -61,7 +61,7 @@ struct bvh_bufs {
     int begin_bits;         // 24 or 32
 };
 
-__global__ __launch_bounds__(256) void k_bvh_heads(bvh_bufs b)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_heads(bvh_bufs b)
 {
     const std::uint32_t c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_bvh_heads(bvh_bufs b)
     b.head[static_cast<std::size_t>(c) * b.n + i] = (i == 0 || codes[i] != codes[i - 1]) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_bvh_run_start(bvh_bufs b)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_run_start(bvh_bufs b)
 {
     const std::uint32_t c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n) {
@@ -100,7 +100,7 @@ CSC_DEV int bvh_delta(const std::uint64_t *codes, const std::uint32_t *rs, std::
     return __clzll(static_cast<long long>(ki ^ kj));
 }
 
-__global__ __launch_bounds__(256) void k_bvh_karras(bvh_bufs b)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_karras(bvh_bufs b)
 {
     const std::uint32_t c = blockIdx.y;
     const std::int64_t i = static_cast<std::int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_bvh_karras(bvh_bufs b)
 }
 
 // Depth by walking the parent chain; sort key (depth, begin); per-level histogram.
-__global__ __launch_bounds__(256) void k_bvh_depth(bvh_bufs b)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_depth(bvh_bufs b)
 {
     __shared__ std::uint32_t hist[BVH_MAX_LEVELS];
     const std::uint32_t c = blockIdx.y;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_bvh_depth(bvh_bufs b)
     }
 }
 
-__global__ void k_bvh_level_off(bvh_bufs b)
+CSC_GLOBAL void k_bvh_level_off(bvh_bufs b)
 {
     const std::uint32_t c = blockIdx.x;
     if (threadIdx.x == 0) {
@@ -219,7 +219,7 @@ __global__ void k_bvh_level_off(bvh_bufs b)
 }
 
 // sval: sorted Karras ids.
-__global__ __launch_bounds__(256) void k_bvh_newidx(bvh_bufs b, const std::uint32_t *sval)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_newidx(bvh_bufs b, const std::uint32_t *sval)
 {
     const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     const std::uint32_t nn = b.n_nodes[c];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_bvh_newidx(bvh_bufs b, const std::uint3
     b.new_of[no + sval[no + p]] = p;
 }
 
-__global__ __launch_bounds__(256) void k_bvh_emit(bvh_bufs b, const std::uint32_t *sval)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_emit(bvh_bufs b, const std::uint32_t *sval)
 {
     const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     const std::uint32_t nn = b.n_nodes[c];
@@ -299,7 +299,7 @@ CSC_DEV float ld_agent(const float *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_bvh_refit(bvh_bufs b)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_refit(bvh_bufs b)
 {
     const std::uint32_t c = blockIdx.y, p0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (p0 >= b.n_nodes[c]) {
@@ -339,7 +339,7 @@ struct bvh_node_ref {
 };
 static_assert(sizeof(bvh_node_ref) == 60, "bvh_node layout");
 
-__global__ __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t chunk, bvh_node_ref *out)
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_export(bvh_bufs b, std::uint32_t chunk, bvh_node_ref *out)
 {
     const std::uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const std::uint32_t nn = b.n_nodes[chunk];
@@ -406,7 +406,7 @@ struct tnode {
 static_assert(sizeof(tnode) == 96, "wide node layout");
 
 // One thread per canonical node; internal nodes fill their record.
-__global__ __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, const std::uint8_t *active,
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, const std::uint8_t *active,
                                                   tnode *tn, std::uint8_t *sact)
 {
     const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -465,7 +465,7 @@ struct pair_lists {
 };
 
 // Group-major list of the pair blocks: order[off[g] + k] = {k-th block of list g, time chunk}.
-__global__ __launch_bounds__(256) void k_pl_order(pair_lists pl, const std::uint32_t *off, uint2 *order)
+CSC_GLOBAL __launch_bounds__(256) void k_pl_order(pair_lists pl, const std::uint32_t *off, uint2 *order)
 {
     const std::uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= pl.nlists) {
@@ -530,7 +530,7 @@ constexpr int BPG_PAIRQ = PB_SIZE + 64; // staged pairs of one wave: one pair bl
 // node index made wave-uniform (v_readlane) the compiler then fetches the 96-byte record with
 // scalar loads (s_load_dwordx8) into SGPRs, and the per-lane box tests take their node
 // operands straight from SGPRs: no LDS traffic and no VGPRs for the broadcast.
-__global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn, bp_params q)
+CSC_GLOBAL __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn, bp_params q)
 {
     __shared__ std::int32_t stack[BPG_STACK];
     __shared__ uint2 pairq[BPG_PAIRQ];
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void k_broad_phase(const tnode *__restrict__ tn
 constexpr int BP_BLOCK = 64;
 constexpr int BP_STACK = 72; // depth <= 64 -> at most 65 pending entries
 
-__global__ __launch_bounds__(BP_BLOCK) void k_broad_phase_stats(bp_params q)
+CSC_GLOBAL __launch_bounds__(BP_BLOCK) void k_broad_phase_stats(bp_params q)
 {
     __shared__ std::int32_t stack[BP_STACK][BP_BLOCK];
     const std::uint32_t c = blockIdx.y;

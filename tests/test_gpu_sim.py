@@ -435,3 +435,60 @@ def test_rows_on_demand_change_nothing(n_par_ct, conj, monkeypatch):
     assert res[0][0] == res[1][0]
     assert np.array_equal(res[0][1], res[1][1])
     assert res[0][2].tobytes() == res[1][2].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tol,order,kind", [(1e-12, 15, "kepler"), (1e-9, 12, "j2drag"), (1e-14, 18, "kepler_events"), (1e-17, 21, "kepler")])
+def test_tolerance_selects_the_taylor_order(orc, tol, order, kind):
+    """kw::tol (src/sim_basic.cpp:553-577; test/sim_api.cpp:54-83 constructs with tol = 1e-12): the
+    Taylor order follows heyoka's rule p = ceil(-ln(tol) / 2 + 1) and the order-p kernels
+    (cascade_order.hip) run the whole step: parity with the oracle at the same order."""
+    from cascade_amd import dynamics, sim
+    from cascade_amd.workloads import leo_si_population, random_leo_pop_kep
+
+    if kind == "j2drag":
+        st, pars = leo_si_population(2500, seed=5)
+        st[:, 6] *= 50.0
+        dyn = dynamics.simple_earth(J2=True, C22S22=False, drag=True)
+        rr = 6378136.3 + 150e3
+        g = sim(st.copy(), 185.5663, dyn=dyn, pars=pars, n_par_ct=4, conj_thresh=5000.0, reentry_radius=rr, tol=tol)
+        o = orc.Sim(st.copy(), 185.5663, n_par_ct=4, conj_thresh=5000.0, dyn_kind=3, mu=dyn.mu, J2=dyn.J2, Re=dyn.Re, reentry_radius=rr, pars=pars, tol=tol)
+    else:
+        st = random_leo_pop_kep(3000, seed=13)
+        st[:, 6] *= 3e4 if kind == "kepler" else 1.0
+        kw = dict(n_par_ct=3, conj_thresh=1e-3)
+        if kind == "kepler_events":
+            kw.update(exit_radius=1.299, reentry_radius=1.0201)
+            keep = (np.linalg.norm(st[:, :3], axis=1) < 1.298) & (np.linalg.norm(st[:, :3], axis=1) > 1.021)
+            st = st[keep]
+        g = sim(st.copy(), 0.23, tol=tol, **kw)
+        o = orc.Sim(st.copy(), 0.23, tol=tol, **kw)
+    assert g.tol == tol and o.order == order
+    n_int = 0
+    for _ in range(5):
+        og, oo = g.step(), o.step()
+        assert og.name == oo
+        assert _ii(g.interrupt_info) == o.interrupt_info
+        assert abs(g.time - o.time) <= RTOL * max(1.0, abs(o.time))
+        assert np.all(np.abs(g.state - o.state) <= RTOL * np.maximum(1.0, np.abs(o.state)))
+        assert g.last_bp_pairs == int(o.stage_times()["n_bp_pairs"])
+        if oo != "success":
+            n_int += 1
+            ii = g.interrupt_info
+            idx = [ii] if isinstance(ii, int) else list(ii)
+            g.remove_particles(idx)
+            o.remove_particles(idx)
+    cg, co = g.conjunctions, o.conjunctions
+    assert len(cg) == len(co)
+    if len(co):
+        assert np.array_equal(cg["i"], co["i"]) and np.array_equal(cg["j"], co["j"])
+        assert np.all(np.abs(cg["time"] - co["time"]) <= RTOL * np.maximum(1.0, np.abs(co["time"])))
+    if kind != "j2drag":
+        assert n_int > 0 or kind == "kepler"
+
+
+def test_tolerance_out_of_range_is_refused():
+    from cascade_amd import sim
+
+    with pytest.raises(ValueError, match="needs Taylor order"):
+        sim(np.array([[1.0, 0, 0, 0, 1.0, 0, 0.0]]), 0.23, tol=1e-1)
