@@ -22,6 +22,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <future>
 #include <thread>
 
 #include <sys/mman.h>
@@ -396,6 +397,11 @@ struct sim::sim_data {
     std::uint32_t shard_rank = 0, shard_n = 1;
     exchange_t exchange;
     gather_t gather; // propagation sharded too when set
+    // Hashes of the host state / parameter vectors as of the last transfer (csc_upload /
+    // csc_download): when they still match at the next step(), the caller has not edited the
+    // arrays and the device copies are current.
+    std::uint64_t state_hash = 0, pars_hash = 0;
+    bool hash_valid = false;
     std::uint64_t step_counter = 0; // step() calls so far (identical on the processes of a sharded simulation)
     std::vector<std::pair<std::uint64_t, std::uint64_t>> conj_segments;
     step_stats stats;
@@ -809,6 +815,7 @@ void sim::set_new_state_pars(std::vector<double> new_state, std::vector<double> 
     m_state = std::move(st);
     m_pars = std::move(ps);
     m_data->dev_rows = -1;
+    m_data->hash_valid = false;
 }
 
 // src/sim_basic.cpp:280-338. With the state resident on the device (host_sync off) the device
@@ -830,6 +837,7 @@ void sim::remove_particles(std::vector<size_type> idxs)
                                    d.get<double>("state"), m_npars, m_npars ? d.get<double>("pars") : nullptr, &n_out));
         d.dev_rows = n_out;
     }
+    m_data->hash_valid = false;
     std::vector<double> new_state, new_pars;
     new_state.reserve((nparts - idxs.size()) * 7u);
     new_pars.reserve((nparts - idxs.size()) * m_npars);
@@ -948,13 +956,15 @@ void sim::upload_state()
     d.ensure_ctx();
     const auto n = get_nparts();
     double *d_state = d.buf<double>("state", n * 7u);
+    d.state_hash = d.pars_hash = 0;
     if (n) {
-        d.chk(csc_memcpy_h2d(d.ctx, d_state, m_state->data(), n * 7u * sizeof(double)));
+        d.chk(csc_upload(d.ctx, d_state, m_state->data(), n * 7u * sizeof(double), &d.state_hash));
     }
     if (m_npars != 0u && n) {
         double *d_pars = d.buf<double>("pars", n * m_npars);
-        d.chk(csc_memcpy_h2d(d.ctx, d_pars, m_pars->data(), n * m_npars * sizeof(double)));
+        d.chk(csc_upload(d.ctx, d_pars, m_pars->data(), n * m_npars * sizeof(double), &d.pars_hash));
     }
+    d.hash_valid = true;
     d.dev_rows = static_cast<std::int64_t>(n);
 }
 
@@ -969,7 +979,7 @@ void sim::download_state()
     // One copy of the whole [n][7] array: the sizes on the device are the host's as of the last
     // upload (only the six coordinates are outputs of a step, copy_from_final_state :1610-1630).
     if (n) {
-        d.chk(csc_memcpy_d2h(d.ctx, m_state->data(), d.buf<double>("state", n * 7u), n * 7u * sizeof(double)));
+        d.chk(csc_download(d.ctx, m_state->data(), d.buf<double>("state", n * 7u), n * 7u * sizeof(double), &d.state_hash));
     }
 }
 
@@ -1045,18 +1055,65 @@ outcome sim::step()
     if (nparts > 0xfffffff0ull) {
         throw std::overflow_error("Overflow detected: the number of particles does not fit 32 bits");
     }
-    const auto n = static_cast<std::uint32_t>(nparts);
-    const std::uint32_t nchunks0 = m_n_par_ct;
-    const double delta_t0 = m_ct * nchunks0;
+    const double delta_t0 = m_ct * m_n_par_ct;
     if (!std::isfinite(delta_t0) || delta_t0 <= 0) {
         throw std::invalid_argument("An invalid superstep size of " + fmt_d(delta_t0) + " was inferred");
     }
     d.ensure_ctx();
-    csc_ctx *ctx = d.ctx;
-    phase_timer pt;
     ++d.step_counter;
 
-    if ((d.host_sync && !(d.in_loop && d.loop_uploaded)) || d.dev_rows != static_cast<std::int64_t>(nparts)) {
+    // The host vectors are the source of truth at every step() entry (the bindings hand out
+    // writable views of them, cascade.py/core.cpp:199-230). When the device still holds the state
+    // of the last transfer, the step runs on it at once while a few host threads check, by hash,
+    // that the caller has not edited the vectors since; nothing user-visible changes before that
+    // check has been confirmed (step_impl calls confirm() before it commits or reports anything),
+    // and an edit sends the step through the upload path instead.
+    const bool want_host = d.host_sync && !(d.in_loop && d.loop_uploaded);
+    const bool dev_valid = d.dev_rows == static_cast<std::int64_t>(nparts);
+    if (want_host && dev_valid && d.hash_valid) {
+        struct stale_state {
+        };
+        std::future<bool> same = std::async(std::launch::async, [&]() {
+            return csc_host_hash(m_state->data(), m_state->size() * sizeof(double)) == d.state_hash
+                   && csc_host_hash(m_pars->data(), m_pars->size() * sizeof(double)) == d.pars_hash;
+        });
+        bool checked = false, unchanged = false;
+        const auto check = [&]() {
+            if (!checked) {
+                unchanged = same.get();
+                checked = true;
+            }
+            return unchanged;
+        };
+        try {
+            const outcome oc = step_impl(false, [&]() {
+                if (!check()) {
+                    throw stale_state{};
+                }
+            });
+            d.loop_uploaded = true;
+            return oc;
+        } catch (const stale_state &) {
+        } catch (...) {
+            if (check()) {
+                throw;
+            }
+        }
+    }
+    return step_impl(want_host || !dev_valid, []() {});
+}
+
+outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
+{
+    auto &d = *m_data;
+    const auto nparts = get_nparts();
+    const auto n = static_cast<std::uint32_t>(nparts);
+    const std::uint32_t nchunks0 = m_n_par_ct;
+    const double delta_t0 = m_ct * nchunks0;
+    csc_ctx *ctx = d.ctx;
+    phase_timer pt;
+
+    if (upload) {
         // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
         for (size_type i = 0; i < nparts; ++i) {
             const double sz = (*m_state)[i * 7u + 6u];
@@ -1212,6 +1269,7 @@ outcome sim::step()
 
     if (summ.n_nf) {
         // :1127-1145: nothing user-visible changes.
+        confirm();
         m_int_info = std::tuple<size_type, double>{summ.nf_idx, summ.nf_time};
         return outcome::err_nf_state;
     }
@@ -1380,6 +1438,7 @@ outcome sim::step()
         oc = (with_exit_event() && summ.ste_ev_idx == 0u) ? outcome::exit : outcome::reentry;
     }
 
+    confirm();
     if (oc == outcome::success) {
         d.time = df_add(d.time, dfloat{delta_t0, 0.});
         d.chk(csc_copy_final_state(ctx, n, d_final, d_state));

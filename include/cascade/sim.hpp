@@ -245,6 +245,7 @@ private:
     [[nodiscard]] bool with_exit_event() const;
     void verify_state_vector(const std::vector<double> &) const;
     void validate_pars_vector(std::vector<double> &, size_type) const;
+    outcome step_impl(bool, const std::function<void()> &);
     void dense_propagate(double);
     void append_conj_data(const void *, std::size_t);
 

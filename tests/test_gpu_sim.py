@@ -492,3 +492,42 @@ def test_tolerance_out_of_range_is_refused():
 
     with pytest.raises(ValueError, match="needs Taylor order"):
         sim(np.array([[1.0, 0, 0, 0, 1.0, 0, 0.0]]), 0.23, tol=1e-1)
+
+
+@pytest.mark.gpu
+def test_host_edits_between_steps_are_honoured_without_any_flag():
+    """The state / pars arrays are the caller's (cascade.py/core.cpp:199-230): default mode, no
+    switch touched. A step on unedited arrays runs on the device copy (checked by hash, no upload)
+    and gives the bits of the resident mode; an in-place edit of the state view or of the pars view
+    between two steps is picked up by the next step; an invalid edit raises the reference's error
+    and leaves everything as it was."""
+    from cascade_amd import dynamics, sim
+    from cascade_amd.workloads import leo_si_population
+
+    n = 120000  # 6.7 MB of state: the pipelined transfer path
+    st, pars = leo_si_population(n, seed=31)
+    kw = dict(dyn=dynamics.simple_earth(J2=True, C22S22=False, drag=True), n_par_ct=2, reentry_radius=6378136.3 + 150e3)
+    a = sim(st.copy(), 185.5663, pars=pars.copy(), **kw)  # default: host arrays authoritative
+    b = sim(st.copy(), 185.5663, pars=pars.copy(), **kw)
+    b.host_sync = False
+    view, pview = a.state, a.pars
+    for k in range(3):
+        assert a.step() == b.step()
+    b.download_state()
+    assert np.array_equal(view, b.state), "unedited steps: same bits as the resident mode"
+    # Edit through views taken BEFORE the steps (zero-copy aliases of the simulation's vectors).
+    view[17, :3] *= 1.3
+    pview[5, 0] = 3e-9
+    c = sim(np.array(view), 185.5663, pars=np.array(pview), **kw)
+    c.time = a.time
+    assert a.step() == c.step()
+    assert np.array_equal(a.state, c.state), "the edited state and parameter were used"
+    assert not np.array_equal(a.state[17], b.state[17])
+    # An invalid edit: the reference's message, nothing changes (src/sim_propagate.cpp:250-253, 513-515).
+    before, t0 = np.array(a.state), a.time
+    view[3, 6] = -1.0
+    with pytest.raises(ValueError, match="An invalid particle size of -1 was detected for the particle at index 3"):
+        a.step()
+    view[3, 6] = before[3, 6]
+    assert np.array_equal(a.state, before) and a.time == t0
+    assert a.step() == c.step() and np.array_equal(a.state, c.state)
