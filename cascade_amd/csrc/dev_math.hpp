@@ -324,8 +324,8 @@ __device__ inline void poly_rescale_p2(double *ret, const double *a, int n)
     }
 }
 
-// Binomial coefficients C(n, k) for n, k <= 20 (exact in double), row-major [21][21].
-constexpr int BINOM_N = 21;
+// Binomial coefficients C(n, k) for n, k <= 24 = the largest Taylor order built (exact in double), row-major.
+constexpr int BINOM_N = 25;
 struct binom_tab {
     double v[BINOM_N * BINOM_N];
 };
