@@ -24,6 +24,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <cascade/logging.hpp>
 #include <cascade/sim.hpp>
 
 namespace py = pybind11;
@@ -387,8 +388,11 @@ PYBIND11_MODULE(core, m)
     static unsigned nthreads = 0;
     m.def("set_nthreads", [](unsigned n) { nthreads = n; }, "n"_a);
     m.def("get_nthreads", []() { return nthreads; });
-    // Logger levels of the reference (cascade.py/logging.cpp:19-29): accepted, no logger here.
-    for (const char *lvl : {"trace", "debug", "info", "warn", "err", "critical"}) {
-        m.def((std::string("set_logger_level_") + lvl).c_str(), []() {});
-    }
+    // Logger levels of the reference (cascade.py/logging.cpp:19-29).
+    m.def("set_logger_level_trace", &cascade::set_logger_level_trace);
+    m.def("set_logger_level_debug", &cascade::set_logger_level_debug);
+    m.def("set_logger_level_info", &cascade::set_logger_level_info);
+    m.def("set_logger_level_warn", &cascade::set_logger_level_warn);
+    m.def("set_logger_level_err", &cascade::set_logger_level_err);
+    m.def("set_logger_level_critical", &cascade::set_logger_level_critical);
 }

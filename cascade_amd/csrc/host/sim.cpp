@@ -10,12 +10,14 @@
 //       -Lcascade_amd -lcascade_hip -Wl,-rpath,'$ORIGIN' -o cascade_amd/libcascade.so
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <map>
 #include <ostream>
@@ -27,6 +29,7 @@
 
 #include <sys/mman.h>
 
+#include <cascade/logging.hpp>
 #include <cascade/sim.hpp>
 #include <cascade_hip.h>
 
@@ -314,6 +317,43 @@ struct phase_timer {
     }
 };
 
+// The "cascade" logger (include/cascade/logging.hpp): levels as spdlog's (trace = 0 ... critical = 5),
+// default info, one line per message on stdout in spdlog's default format.
+std::atomic<int> g_log_level{2};
+enum : int { LOG_TRACE = 0, LOG_DEBUG = 1, LOG_INFO = 2, LOG_WARN = 3 };
+
+bool log_on(int lvl)
+{
+    return lvl >= g_log_level.load(std::memory_order_relaxed);
+}
+
+void log_line(int lvl, const std::string &msg)
+{
+    if (!log_on(lvl)) {
+        return;
+    }
+    static const char *names[] = {"trace", "debug", "info", "warning", "error", "critical"};
+    const auto now = std::chrono::system_clock::now();
+    const std::time_t tt = std::chrono::system_clock::to_time_t(now);
+    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now.time_since_epoch()).count() % 1000;
+    std::tm tmv{};
+    localtime_r(&tt, &tmv);
+    char stamp[32];
+    std::strftime(stamp, sizeof(stamp), "%Y-%m-%d %H:%M:%S", &tmv);
+    std::fprintf(stdout, "[%s.%03d] [cascade] [%s] %s\n", stamp, static_cast<int>(ms), names[lvl], msg.c_str());
+    std::fflush(stdout);
+}
+
+// spdlog::stopwatch of the reference's phases; `sync` finishes the queued device work first, so
+// that a phase's line holds the time of that phase (only called at trace level).
+struct stopwatch {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    [[nodiscard]] std::string elapsed() const
+    {
+        return fmt_d(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // First touch of a large stretch of freshly reserved (not yet constructed) vector storage by
 // several threads: a conjunction-heavy superstep appends gigabytes of records, and a single
 // thread faulting the pages in while it copies runs at a fraction of the memory bandwidth.
@@ -496,6 +536,31 @@ struct sim::sim_data {
         return static_cast<T *>(bufs[name].p);
     }
 };
+
+void set_logger_level_trace()
+{
+    g_log_level = 0;
+}
+void set_logger_level_debug()
+{
+    g_log_level = 1;
+}
+void set_logger_level_info()
+{
+    g_log_level = 2;
+}
+void set_logger_level_warn()
+{
+    g_log_level = 3;
+}
+void set_logger_level_err()
+{
+    g_log_level = 4;
+}
+void set_logger_level_critical()
+{
+    g_log_level = 5;
+}
 
 sim::sim(ptag_t, std::vector<double> state, double ct)
     : m_state(std::make_shared<std::vector<double>>(std::move(state))), m_pars(std::make_shared<std::vector<double>>()),
@@ -989,6 +1054,7 @@ void sim::download_state()
 void sim::append_conj_data(const void *recs, std::size_t n)
 {
     static_assert(sizeof(conjunction) == sizeof(csc_conjunction), "conjunction layout");
+    const stopwatch sw_append;
     // src/sim_narrow_phase.cpp:999-1011: when the vector cannot take the new records, a NEW one
     // with twice the needed capacity replaces it (arrays handed out earlier keep the old one
     // alive); otherwise the records are appended in place.
@@ -1006,12 +1072,14 @@ void sim::append_conj_data(const void *recs, std::size_t n)
     if (n) {
         m_data->conj_segments.emplace_back(m_data->step_counter, n);
     }
+    log_line(LOG_TRACE, "Runtime for append_conj_data(): " + sw_append.elapsed() + "s");
 }
 
 // dense_propagate (src/sim_propagate.cpp:1386-1503) + copy_from_final_state.
 void sim::dense_propagate(double t)
 {
     auto &d = *m_data;
+    const stopwatch sw_dense;
     const auto n = static_cast<std::uint32_t>(get_nparts());
     if (!d.rows_full) {
         // Rows on demand: only the particles of the candidate pairs have theirs. The state on the
@@ -1041,6 +1109,10 @@ void sim::dense_propagate(double t)
     d.state_prestep = false;
     if (d.host_sync && !d.in_loop) {
         download_state();
+    }
+    if (log_on(LOG_TRACE)) {
+        d.chk(csc_sync(d.ctx));
+        log_line(LOG_TRACE, "Dense propagation time: " + sw_dense.elapsed() + "s");
     }
 }
 
@@ -1112,6 +1184,11 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     const double delta_t0 = m_ct * nchunks0;
     csc_ctx *ctx = d.ctx;
     phase_timer pt;
+    const bool tracing = log_on(LOG_TRACE);
+    const stopwatch sw_total;
+    log_line(LOG_TRACE, "---- STEP BEGIN ---");
+    log_line(LOG_TRACE, "Number of chunks: " + std::to_string(nchunks0));
+    stopwatch sw;
 
     if (upload) {
         // src/sim_propagate.cpp:250-253 (message pinned by test/invalid_state.cpp:48-49)
@@ -1262,6 +1339,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
     pt.lap("propagate");
+    log_line(LOG_TRACE, "Propagation + AABB computation time: " + sw.elapsed() + "s");
     d.row_hint = summ.max_substeps;
     d.row_hint_ct = m_ct;
     d.row_hint_nchunks = nchunks0;
@@ -1271,6 +1349,10 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         // :1127-1145: nothing user-visible changes.
         confirm();
         m_int_info = std::tuple<size_type, double>{summ.nf_idx, summ.nf_time};
+        log_line(LOG_DEBUG, "The step function was interrupted due to particle " + std::to_string(summ.nf_idx)
+                                + " generating a non-finite state during the numerical integration");
+        log_line(LOG_TRACE, "Total propagation time: " + sw_total.elapsed() + "s");
+        log_line(LOG_TRACE, "---- STEP END ---");
         return outcome::err_nf_state;
     }
     if (summ.flags & CSC_ST_FLAG_BAD_AABB) {
@@ -1298,16 +1380,34 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         nchunks = std::min(new_nchunks, nchunks0);
     }
 
+    sw = stopwatch{};
     d.chk(csc_global_aabb(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub));
     d.chk(csc_morton_encode(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes));
     d.chk(csc_sort_gather(ctx, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs));
 
+    if (tracing) {
+        d.chk(csc_sync(ctx));
+        log_line(LOG_TRACE, "Morton encoding and sorting time: " + sw.elapsed() + "s");
+        sw = stopwatch{};
+    }
     const std::uint64_t tot = summ.total_substeps;
     d.last_cfg = cfg;
     d.chk(csc_bvh_build(ctx, n, nchunks, d_scodes, d_slbs, d_subs));
+    if (tracing) {
+        d.chk(csc_sync(ctx));
+        log_line(LOG_TRACE, "BVH construction time: " + sw.elapsed() + "s");
+        sw = stopwatch{};
+    }
     std::uint64_t npairs = 0;
     d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));
     d.chk(csc_broad_phase(ctx, n, nchunks, d_slbs, d_subs, d_vidx, d_active, &npairs));
+    if (tracing) {
+        // src/sim_broad_phase.cpp:209-213 (with a sharded simulation: this process's share)
+        log_line(LOG_TRACE, "Broad phase collision detection time: " + sw.elapsed() + "s");
+        log_line(LOG_TRACE, "Average number of AABB collisions per particle per chunk: "
+                                + fmt_d(static_cast<double>(npairs) / static_cast<double>(nchunks) / static_cast<double>(n)));
+        sw = stopwatch{};
+    }
     {
         const int rc = csc_check_flags(ctx);
         if (rc == CSC_ERR_NONFINITE_AABB) {
@@ -1375,6 +1475,20 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     std::uint64_t ncoll_v = 0, nconj_v = 0;
     d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
     pt.lap("narrow");
+    if (tracing) {
+        // src/sim_narrow_phase.cpp:1017-1021
+        log_line(LOG_TRACE, "Narrow phase collision detection time: " + sw.elapsed() + "s");
+        log_line(LOG_TRACE, "Total number of collisions detected: " + std::to_string(ncoll_v));
+        if (with_conj) {
+            log_line(LOG_TRACE, "Total number of conjunctions detected: " + std::to_string(nconj_v));
+        }
+    }
+    if (warn != 0u) {
+        // src/sim_narrow_phase.cpp:373-381, 410-417: root-finder give-ups are warnings, the pair is skipped.
+        log_line(LOG_WARN, "Polynomial root finding during collision/conjunction detection failed or produced non-finite "
+                           "values for some pairs of this step, which were skipped (flags "
+                               + std::to_string(warn) + ")");
+    }
 
     d.stats.bp_pairs = npairs;
     d.stats.bp_node_pairs = csc_broad_phase_node_pairs(ctx);
@@ -1468,6 +1582,8 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
             append_conj_data(conj_p, static_cast<std::size_t>(last - conj_p));
         }
     }
+    log_line(LOG_TRACE, "Total propagation time: " + sw_total.elapsed() + "s");
+    log_line(LOG_TRACE, "---- STEP END ---");
     return oc;
 }
 

@@ -80,3 +80,20 @@ def test_workload_generator():
     a0 = (1.3 - 1.02) * ((1608637542.0 + 3421126067.0 * 4294967296.0) / 18446744073709551616.0) + 1.02
     x = np.linalg.norm(st[0, :3])
     assert abs(x - a0) < 0.03 * a0  # r within e of a
+
+
+def test_import_cascade_alias():
+    """`import cascade` (the reference's package name, cascade.py/__init__.py:47-61) gives the
+    same classes; the six logger setters of cascade.py/logging.cpp:19-29 exist and are callable."""
+    import cascade
+    import cascade.dynamics
+    import cascade_amd
+
+    assert cascade.sim is cascade_amd.sim and cascade.outcome is cascade_amd.outcome
+    assert cascade.dynamics.kepler(1.0).kind == 0
+    for lvl in ("trace", "debug", "info", "warn", "err", "critical"):
+        getattr(cascade, "set_logger_level_" + lvl)()
+    cascade.set_logger_level_info()
+    cascade.set_nthreads(3)
+    assert cascade.get_nthreads() == 3
+    cascade.set_nthreads(0)

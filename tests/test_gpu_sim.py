@@ -531,3 +531,41 @@ def test_host_edits_between_steps_are_honoured_without_any_flag():
     view[3, 6] = before[3, 6]
     assert np.array_equal(a.state, before) and a.time == t0
     assert a.step() == c.step() and np.array_equal(a.state, c.state)
+
+
+@pytest.mark.gpu
+def test_trace_log_lines(capfd):
+    """At trace level step() prints the reference's per-phase lines (sample in
+    cascade.py/docstrings.cpp:581-596), including the tuning signal "Average number of AABB
+    collisions per particle per chunk" (src/sim_broad_phase.cpp:211-213) with the right value."""
+    import re
+
+    import cascade
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(5000, seed=2)
+    s = cascade.sim(st, 0.23, n_par_ct=2, conj_thresh=1e-3)
+    cascade.set_logger_level_trace()
+    try:
+        s.step()
+    finally:
+        cascade.set_logger_level_info()
+    out = capfd.readouterr().out
+    for what in (
+        "---- STEP BEGIN ---",
+        "Number of chunks: 2",
+        "Propagation + AABB computation time: ",
+        "Morton encoding and sorting time: ",
+        "BVH construction time: ",
+        "Broad phase collision detection time: ",
+        "Narrow phase collision detection time: ",
+        "Total number of collisions detected: 0",
+        "Total number of conjunctions detected: ",
+        "Total propagation time: ",
+        "---- STEP END ---",
+    ):
+        assert "[cascade] [trace] " + what in out, what
+    m = re.search(r"Average number of AABB collisions per particle per chunk: ([0-9.e+-]+)", out)
+    assert m and abs(float(m.group(1)) - s.last_bp_pairs / 2 / 5000) < 1e-9
+    s.step()
+    assert "[cascade]" not in capfd.readouterr().out, "silent at the default level"
