@@ -289,7 +289,19 @@ CSC_GLOBAL __launch_bounds__(256) void k_bvh_emit(bvh_bufs b, const std::uint32_
 // storing wave waits for them (s_waitcnt vmcnt(0)) and only then bumps the node's counter with
 // an agent-scope atomic; the thread whose add came last reads the child boxes with agent-scope
 // (sc1) loads issued after its add has returned. No cache-wide fence is involved: a
-// __threadfence() here costs an L2 write-back per call (measured: 6 ms instead of 0.05 ms).
+// __threadfence() here costs an L2 write-back per call (measured: 6 ms instead of 0.05 ms), and
+// so would a release / acquire pair on visit[] (an agent-scope release is that same L2
+// write-back on gfx950, whose L2s are per XCD).
+// ISA this relies on (outside the HIP memory model, which has no edge between relaxed atomics):
+//   global_store_dword ... sc1   the box goes through to memory, past the XCD's own L2;
+//   s_waitcnt vmcnt(0)           gfx9 counts stores in vmcnt: the stores have been acknowledged
+//                                before the add is issued;
+//   global_atomic_add ... sc0    performed at the memory side, returns the arrival order;
+//   global_load_dword ... sc1    issued after the add has returned, misses the XCD's L2.
+// tests/test_capi_symbols.py::test_refit_handoff_isa disassembles the built kernel and checks
+// exactly these properties, so a toolchain that lowers the atomics differently fails the CPU
+// suite; tests/test_gpu_fullsize.py and test_gpu_parity.py check the boxes themselves (exact
+// unions, byte-identical trees) on many sizes and chunk counts.
 CSC_DEV void st_agent(float *p, float v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,12 +332,22 @@ CSC_GLOBAL __launch_bounds__(256) void k_bvh_refit(bvh_bufs b)
         const std::int32_t l = b.nleft[no + cur];
         const float *la = reinterpret_cast<const float *>(b.nlb + no + l), *ua = reinterpret_cast<const float *>(b.nub + no + l);
         float *lo = reinterpret_cast<float *>(b.nlb + no + cur), *uo = reinterpret_cast<float *>(b.nub + no + cur);
+        // All sixteen loads are issued before the first value is used (one memory round trip per
+        // level instead of eight: each store depends on its loads and the compiler waits for
+        // everything outstanding in front of it).
+        float cl[8], cu[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cl[k] = ld_agent(la + k);
+            cu[k] = ld_agent(ua + k);
+        }
+        const std::int32_t up = b.npar[no + cur];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            st_agent(lo + k, fminf_std(ld_agent(la + k), ld_agent(la + 4 + k)));
-            st_agent(uo + k, fmaxf_std(ld_agent(ua + k), ld_agent(ua + 4 + k)));
+            st_agent(lo + k, fminf_std(cl[k], cl[4 + k]));
+            st_agent(uo + k, fmaxf_std(cu[k], cu[4 + k]));
         }
-        cur = b.npar[no + cur];
+        cur = up;
     }
 }
 

@@ -97,3 +97,47 @@ def test_import_cascade_alias():
     cascade.set_nthreads(3)
     assert cascade.get_nthreads() == 3
     cascade.set_nthreads(0)
+
+
+def test_refit_handoff_isa():
+    """k_bvh_refit (cascade_amd/csrc/k_bvh.hpp) hands child boxes between waves on different XCDs
+    with relaxed agent-scope atomics and one s_waitcnt, relying on how gfx950 executes them: the
+    box stores and loads must carry sc1 (write-through / L2 bypass), the arrival counter must be a
+    returning global atomic, and a `s_waitcnt vmcnt(0)` must sit between the last box store of a
+    level and the atomic. Checked on the ISA of the built object, so that a toolchain update that
+    lowers them differently is caught here and not by a silently stale parent box."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    import __graft_entry__ as g
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "build", "cascade_hip.o")
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    if not os.path.exists(obj):
+        g.build_hip()
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "cascade_hip.o")
+        shutil.copy(obj, local)
+        subprocess.check_call([objdump, "--offloading", local], cwd=tmp, stdout=subprocess.DEVNULL)
+        dev = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert dev, os.listdir(tmp)
+        asm = subprocess.check_output([objdump, "-d", "--no-show-raw-insn", os.path.join(tmp, dev[0])], text=True)
+    lines = asm.splitlines()
+    start = next(i for i, l in enumerate(lines) if "k_bvh_refit" in l and l.rstrip().endswith(">:"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = [l.split("//")[0].strip() for l in lines[start:end]]
+    mem = [l for l in body if l.startswith(("global_", "flat_", "buffer_", "s_waitcnt vmcnt"))]
+    atom = [i for i, l in enumerate(mem) if l.startswith("global_atomic_add")]
+    assert len(atom) == 1 and "sc0" in mem[atom[0]], mem  # one returning atomic: the arrival counter
+    stores = [l for l in mem if l.startswith("global_store")]
+    assert len(stores) == 8 and all("sc1" in l for l in stores), stores
+    after = [l for l in mem[atom[0] + 1 :] if l.startswith("global_load")]
+    box_loads = [l for l in after if "sc1" in l]
+    assert len(box_loads) == 16, after  # the two child boxes, agent scope
+    # The loop closes on the atomic: between the last box store and the atomic (wrapping around)
+    # there is a wait for all outstanding vector memory operations.
+    assert mem[atom[0] - 1].startswith("s_waitcnt vmcnt(0)"), mem[: atom[0] + 1]
+    assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in body), "no cache-wide fences"
