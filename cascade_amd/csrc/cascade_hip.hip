@@ -105,6 +105,7 @@ struct csc_ctx {
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
     uint32_t np_attempts = 0;   // passes the last narrow-phase call needed (1 = no list overflowed)
     int dt_levels = 0;          // levels with a non-empty frontier in the last dual traversal
+    std::vector<uint64_t> dt_level_items; // frontier size of every level of the last dual traversal (grid sizing)
     // csc_narrow_phase_prefilter -> csc_narrow_phase_finish: the candidate list left on the device
     const uint4 *np_cand_list = nullptr;
     uint64_t np_cand_count = 0;
@@ -1645,7 +1646,16 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
                 q.out = (level % 2 == 0) ? d_fb : d_fa;
                 q.in_cnt = d_cnt + ctr_per_level * level;
                 q.out_cnt = d_cnt + ctr_per_level * (level + 1);
-                hipLaunchKernelGGL(k_bp_dual, dim3(grid), dim3(DT_BLOCK), 0, ctx->stream, q);
+                // Workgroups for this level: what its frontier needed last time (+50 %), at most
+                // `grid`; the tiles are strided over, so a frontier that grew is still covered.
+                // (16384 workgroups that find nothing to do cost 6 us per level, and half of the
+                // ~32 levels hold a few thousand items.)
+                unsigned g = grid;
+                if (static_cast<size_t>(level) < ctx->dt_level_items.size() && !std::getenv("CASCADE_DT_GRID")) {
+                    const uint64_t want = cdiv(ctx->dt_level_items[level] * 3u / 2u + 1u, static_cast<uint64_t>(DT_SHARDS) * DT_BLOCK);
+                    g = DT_SHARDS * static_cast<unsigned>(std::min<uint64_t>(std::max<uint64_t>(want, 1u), per_shard));
+                }
+                hipLaunchKernelGGL(k_bp_dual, dim3(g), dim3(DT_BLOCK), 0, ctx->stream, q);
             }
             CSC_LAUNCH_CHECK();
             CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * level, d_cnt + ctr_per_level * level, ctr_per_level * sizeof(uint32_t),
@@ -1668,6 +1678,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         uint32_t max_fr = 0, max_pr = 0;
         uint64_t items = 0;
         int used_levels = 0;
+        ctx->dt_level_items.assign(static_cast<size_t>(level) + 1u, 0);
         for (int l = 0; l <= level; ++l) {
             uint64_t at_level = 0;
             for (int s = 0; s < DT_SHARDS; ++s) {
@@ -1676,6 +1687,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
                 at_level += v;
             }
             items += at_level;
+            ctx->dt_level_items[l] = at_level;
             if (at_level) {
                 used_levels = l + 1;
             }

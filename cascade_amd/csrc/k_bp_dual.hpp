@@ -149,16 +149,45 @@ __global__ void k_bp_dual_init(std::uint32_t nchunks, std::uint32_t nn_max, cons
     }
 }
 
+// A child of one side of an item (or the carried leaf itself): box, what an item stores for it
+// (value, kind), original index and activity flags of its first particle. Plain scalars: the four
+// kids of an item must stay in registers (no arrays, no addresses taken).
+struct dt_kid {
+    float4 lb, ub;
+    std::uint32_t val, kind, orig, act;
+};
+
+CSC_DEV dt_kid dt_kid_from_desc(const float4 &lb, const float4 &ub, const int4 &c)
+{
+    dt_kid s;
+    s.lb = lb;
+    s.ub = ub;
+    const bool leaf = c.x < 0;
+    const std::uint32_t code = static_cast<std::uint32_t>(-1 - c.x);
+    const std::uint32_t begin = static_cast<std::uint32_t>(c.y), end = static_cast<std::uint32_t>(c.z);
+    s.kind = !leaf ? DT_INTERNAL : (end - begin == 1u ? DT_LEAF1 : DT_LEAFN);
+    s.val = !leaf ? static_cast<std::uint32_t>(c.x) : (end - begin == 1u ? begin : (code >> 2));
+    s.act = code & 3u;
+    s.orig = static_cast<std::uint32_t>(c.w);
+    return s;
+}
+
+// Every lane runs the SAME code whatever the kinds of its item (internal x internal, carried leaf
+// x internal, self pair): only the loads of a side differ. Up to four child pairs (i, j), slot
+// 2 i + j; outputs are compacted slot by slot with wave ballots (position = outputs of the
+// earlier slots of the workgroup + lanes before me in this slot), one atomic per workgroup tile
+// and output kind.
 __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
 {
-    __shared__ std::uint32_t s_wsum[2][DT_BLOCK / 64];
+    constexpr int NW = DT_BLOCK / 64;
+    __shared__ std::uint32_t s_cnt[2][NW][4];
     __shared__ std::uint32_t s_base[2];
     const std::uint32_t shard = blockIdx.x % DT_SHARDS;
     const std::uint32_t tile_stride = gridDim.x / DT_SHARDS;
     const std::uint32_t cnt_raw = q.in_cnt[shard * DT_CTR_STRIDE];
     const std::uint32_t cnt = cnt_raw < q.fr_cap ? cnt_raw : q.fr_cap;
     const unsigned long long *in = q.in + static_cast<std::size_t>(shard) * q.fr_cap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
     const bool deal_pairs = q.shard_n > 1u && q.level < q.shard_level;
     const bool deal_items = q.shard_n > 1u && q.level + 1u == q.shard_level;
 
@@ -171,8 +200,7 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
         unsigned long long *pout = q.pairs + static_cast<std::size_t>(oshard) * q.pair_cap;
         std::uint32_t *out_cnt = q.out_cnt + oshard * DT_CTR_STRIDE;
         std::uint32_t *pair_cnt = q.pair_cnt + oshard * DT_CTR_STRIDE;
-        // Up to four outputs, one per (statically numbered) child pair: kind 1 = frontier item,
-        // 2 = pair. Static slots keep the records in registers.
+        // One output per (statically numbered) child pair: kind 1 = frontier item, 2 = pair.
         unsigned long long rec_out[4] = {0, 0, 0, 0};
         std::uint32_t kind[4] = {0, 0, 0, 0};
         if (k < cnt) {
@@ -181,25 +209,38 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
             const std::uint32_t ak = static_cast<std::uint32_t>(it >> 26) & 3u;
             const std::uint32_t b = static_cast<std::uint32_t>(it >> 28) & (DT_MAX_NODES - 1u);
             const std::uint32_t bk = static_cast<std::uint32_t>(it >> 54) & 3u;
-            const bool al = ak != DT_INTERNAL, bl = bk != DT_INTERNAL;
             const std::uint32_t c = static_cast<std::uint32_t>(it >> 56);
             const std::size_t no = static_cast<std::size_t>(c) * q.nn_max, po = static_cast<std::size_t>(c) * q.n;
             const tnode *tn = q.tn + no;
+            const bool self = a == b && ak == bk;
 
+            // Particle range of a leaf child (multi-particle leaves: rare, equal Morton codes).
+            auto range_of = [&](std::uint32_t v, std::uint32_t kd, std::uint32_t &rb, std::uint32_t &re) {
+                if (kd == DT_LEAF1) {
+                    rb = v;
+                    re = v + 1u;
+                } else {
+                    rb = q.nb[no + v];
+                    re = q.ne[no + v];
+                }
+            };
             // Exact leaf-leaf test of the reference for every member pair (multi-particle leaves:
             // the particle with the smaller original index queries the LEAF box of the other,
             // src/sim_broad_phase.cpp:161-185). Rare: appended one by one.
-            auto slow_pairs = [&](const dt_side &x, const dt_side &y, bool same) {
-                for (std::uint32_t p = x.begin; p != x.end; ++p) {
-                    for (std::uint32_t r = same ? p + 1u : y.begin; r != y.end; ++r) {
+            auto slow_pairs = [&](const dt_kid x, const dt_kid y, bool same) {
+                std::uint32_t xb, xe, yb, ye;
+                range_of(x.val, x.kind, xb, xe);
+                range_of(y.val, y.kind, yb, ye);
+                for (std::uint32_t p = xb; p != xe; ++p) {
+                    for (std::uint32_t r = same ? p + 1u : yb; r != ye; ++r) {
                         const std::uint32_t op = q.vidx[po + p], orr = q.vidx[po + r];
                         if ((q.active[op] | q.active[orr]) == 0) {
                             continue;
                         }
                         const bool p_first = op < orr;
                         const std::uint32_t qa = p_first ? p : r, qb = p_first ? r : p;
-                        const dt_side &leaf_b = p_first ? y : x;
-                        if (!same && !bp_overlap(q.slb[po + qa], q.sub[po + qa], leaf_b.lb, leaf_b.ub)) {
+                        const float4 llb = p_first ? y.lb : x.lb, lub = p_first ? y.ub : x.ub;
+                        if (!same && !bp_overlap(q.slb[po + qa], q.sub[po + qa], llb, lub)) {
                             continue;
                         }
                         const unsigned long long rec = dt_pair(qa, qb, c);
@@ -213,124 +254,117 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
                     }
                 }
             };
-            // A pair of distinct nodes whose boxes overlap.
-            auto visit = [&](const dt_side &x, const dt_side &y, const int slot) {
-                if (x.leaf && y.leaf) {
-                    if (x.end - x.begin == 1u && y.end - y.begin == 1u) {
-                        if ((x.act | y.act) != 0u) {
-                            const bool x_first = x.orig < y.orig;
-                            const unsigned long long rec = dt_pair(x_first ? x.begin : y.begin, x_first ? y.begin : x.begin, c);
-                            if (!deal_pairs || dt_hash(rec) % q.shard_n == q.shard_rank) {
-                                rec_out[slot] = rec;
-                                kind[slot] = 2u;
-                            }
-                        }
+            // The two kids of a side: x1 valid only for internal nodes.
+            auto load_side = [&](std::uint32_t v, std::uint32_t kd, dt_kid &x0, dt_kid &x1) {
+                if (kd == DT_INTERNAL) {
+                    const tnode t = tn[v];
+                    x0 = dt_kid_from_desc(t.lb0, t.ub0, t.c0);
+                    x1 = dt_kid_from_desc(t.lb1, t.ub1, t.c1);
+                } else {
+                    x0.kind = kd;
+                    x0.val = v;
+                    if (kd == DT_LEAF1) {
+                        // v = sorted position: the leaf box is the particle's box; independent loads.
+                        x0.lb = q.slb[po + v];
+                        x0.ub = q.sub[po + v];
+                        x0.orig = q.vidx[po + v];
+                        x0.act = q.sact[po + v];
                     } else {
-                        slow_pairs(x, y, false);
+                        x0.lb = q.nlb[no + v];
+                        x0.ub = q.nub[no + v];
+                        x0.orig = q.vidx[po + q.nb[no + v]];
+                        x0.act = q.active[x0.orig];
                     }
+                    x1 = x0;
+                }
+            };
+            // One child pair; slot numbers are compile-time constants at every call.
+            auto pair_of = [&](const dt_kid &x, const dt_kid &y, bool go, bool self_kid, const int slot) {
+                go = go && (self_kid || bp_overlap(x.lb, x.ub, y.lb, y.ub));
+                if (!go) {
+                    return;
+                }
+                if (self_kid) {
+                    // (a single-particle leaf has no pair with itself)
+                    if (x.kind != DT_LEAF1) {
+                        const unsigned long long rec = dt_item(x.val, x.kind, x.val, x.kind, c);
+                        if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                            rec_out[slot] = rec;
+                            kind[slot] = 1u;
+                        }
+                    }
+                } else if (x.kind == DT_LEAF1 && y.kind == DT_LEAF1) {
+                    if ((x.act | y.act) != 0u) {
+                        const bool x_first = x.orig < y.orig;
+                        const unsigned long long rec = dt_pair(x_first ? x.val : y.val, x_first ? y.val : x.val, c);
+                        if (!deal_pairs || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                            rec_out[slot] = rec;
+                            kind[slot] = 2u;
+                        }
+                    }
+                } else if (x.kind != DT_INTERNAL && y.kind != DT_INTERNAL) {
+                    slow_pairs(x, y, false);
                 } else {
-                    const unsigned long long rec = dt_item(x.value(), x.kind(), y.value(), y.kind(), c);
+                    const unsigned long long rec = dt_item(x.val, x.kind, y.val, y.kind, c);
                     if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
                         rec_out[slot] = rec;
                         kind[slot] = 1u;
                     }
                 }
-            };
-            auto self = [&](const dt_side &x, const int slot) {
-                if (!x.leaf || x.end - x.begin > 1u) {
-                    const unsigned long long rec = dt_item(x.idx, x.kind(), x.idx, x.kind(), c);
-                    if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
-                        rec_out[slot] = rec;
-                        kind[slot] = 1u;
-                    }
-                }
-            };
-            // A leaf carried over from the level above.
-            auto carried_leaf = [&](std::uint32_t v, std::uint32_t kd) {
-                dt_side s;
-                s.leaf = true;
-                if (kd == DT_LEAF1) {
-                    // v = sorted position: the leaf box is the particle's box; independent loads.
-                    s.lb = q.slb[po + v];
-                    s.ub = q.sub[po + v];
-                    s.idx = 0u;
-                    s.begin = v;
-                    s.end = v + 1u;
-                    s.orig = q.vidx[po + v];
-                    s.act = q.sact[po + v];
-                } else {
-                    s.lb = q.nlb[no + v];
-                    s.ub = q.nub[no + v];
-                    s.idx = v;
-                    s.begin = q.nb[no + v];
-                    s.end = q.ne[no + v];
-                    s.orig = q.vidx[po + s.begin];
-                    s.act = q.active[s.orig];
-                }
-                return s;
             };
 
-            if (a == b && ak == bk) {
-                if (al) {
-                    const dt_side x = carried_leaf(a, ak);
-                    slow_pairs(x, x, true);
-                } else {
-                    const tnode t = tn[a];
-                    const dt_side x0 = dt_child(t.lb0, t.ub0, t.c0), x1 = dt_child(t.lb1, t.ub1, t.c1);
-                    self(x0, 0);
-                    self(x1, 1);
-                    if (bp_overlap(x0.lb, x0.ub, x1.lb, x1.ub)) {
-                        visit(x0, x1, 2);
-                    }
-                }
-            } else if (!al && !bl) {
-                const tnode ta = tn[a], tb = tn[b];
-                const dt_side x0 = dt_child(ta.lb0, ta.ub0, ta.c0), x1 = dt_child(ta.lb1, ta.ub1, ta.c1);
-                const dt_side y0 = dt_child(tb.lb0, tb.ub0, tb.c0), y1 = dt_child(tb.lb1, tb.ub1, tb.c1);
-                if (bp_overlap(x0.lb, x0.ub, y0.lb, y0.ub)) {
-                    visit(x0, y0, 0);
-                }
-                if (bp_overlap(x0.lb, x0.ub, y1.lb, y1.ub)) {
-                    visit(x0, y1, 1);
-                }
-                if (bp_overlap(x1.lb, x1.ub, y0.lb, y0.ub)) {
-                    visit(x1, y0, 2);
-                }
-                if (bp_overlap(x1.lb, x1.ub, y1.lb, y1.ub)) {
-                    visit(x1, y1, 3);
-                }
+            dt_kid A0, A1, B0, B1;
+            load_side(a, ak, A0, A1);
+            if (self && ak != DT_INTERNAL) {
+                // A multi-particle leaf against itself.
+                slow_pairs(A0, A0, true);
             } else {
-                // One leaf carried over, one internal node.
-                const std::uint32_t li = al ? a : b, ni = al ? b : a;
-                const dt_side x = carried_leaf(li, al ? ak : bk);
-                const tnode t = tn[ni];
-                const dt_side y0 = dt_child(t.lb0, t.ub0, t.c0), y1 = dt_child(t.lb1, t.ub1, t.c1);
-                if (bp_overlap(x.lb, x.ub, y0.lb, y0.ub)) {
-                    visit(x, y0, 0);
+                if (self) {
+                    B0 = A0;
+                    B1 = A1;
+                } else {
+                    load_side(b, bk, B0, B1);
                 }
-                if (bp_overlap(x.lb, x.ub, y1.lb, y1.ub)) {
-                    visit(x, y1, 1);
-                }
+                const bool a2 = ak == DT_INTERNAL, b2 = bk == DT_INTERNAL;
+                pair_of(A0, B0, true, self, 0);
+                pair_of(A0, B1, b2, false, 1);
+                pair_of(A1, B0, a2 && !self, false, 2); // (self items: (A1, A0) is (A0, A1) again)
+                pair_of(A1, B1, a2 && b2, self, 3);
             }
         }
 
-        // Workgroup compaction of both outputs: one atomic per output kind and tile.
+        // Compaction in lane order (the children of one item stay next to each other: the lanes of
+        // the next level then share node records). A lane has 0..4 outputs of a kind: its offset
+        // within the wave is the sum over the three bits of that count of (1 << bit) x the number
+        // of earlier lanes with the bit set -- three ballots per kind, no shuffles.
         std::uint32_t nf = 0, np = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             nf += kind[j] == 1u;
             np += kind[j] == 2u;
         }
-        const std::uint32_t inc_f = dt_wave_incl_scan(nf, lane), inc_p = dt_wave_incl_scan(np, lane);
-        if (lane == 63) {
-            s_wsum[0][wave] = inc_f;
-            s_wsum[1][wave] = inc_p;
+        auto lane_prefix = [](std::uint32_t v, std::uint32_t &wave_total) {
+            std::uint32_t pre = 0;
+            wave_total = 0;
+#pragma unroll
+            for (int bit = 0; bit < 3; ++bit) {
+                const unsigned long long m = __ballot(((v >> bit) & 1u) != 0u);
+                pre += __builtin_amdgcn_mbcnt_hi(static_cast<std::uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<std::uint32_t>(m), 0u)) << bit;
+                wave_total += static_cast<std::uint32_t>(__popcll(m)) << bit;
+            }
+            return pre;
+        };
+        std::uint32_t wt_f, wt_p;
+        std::uint32_t off_f = lane_prefix(nf, wt_f), off_p = lane_prefix(np, wt_p);
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[0][wave][0] = wt_f;
+            s_cnt[1][wave][0] = wt_p;
         }
         __syncthreads();
-        std::uint32_t off_f = inc_f - nf, off_p = inc_p - np, tot_f = 0, tot_p = 0;
+        std::uint32_t tot_f = 0, tot_p = 0;
 #pragma unroll
-        for (int w = 0; w < DT_BLOCK / 64; ++w) {
-            const std::uint32_t wf = s_wsum[0][w], wp = s_wsum[1][w];
+        for (int w = 0; w < NW; ++w) {
+            const std::uint32_t wf = s_cnt[0][w][0], wp = s_cnt[1][w][0];
             if (w < wave) {
                 off_f += wf;
                 off_p += wp;

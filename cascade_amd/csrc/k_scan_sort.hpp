@@ -144,7 +144,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const std::uint32_t *
 // ---------------------------------------------------------------------------
 constexpr int RS_BLOCK = 256;
 constexpr int RS_WAVES = RS_BLOCK / 64;
-constexpr int RS_ITEMS = 16;
+constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per block
 constexpr int RS_BINS = 256;
 
