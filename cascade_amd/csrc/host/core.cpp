@@ -302,6 +302,8 @@ PYBIND11_MODULE(core, m)
                  return oss.str();
              })
         // ---- additions of this build (measurement and residency control) ---------------
+        .def("__copy__", [](const sim &s) { return sim(s); })
+        .def("__deepcopy__", [](const sim &s, py::dict) { return sim(s); }, "memo"_a)
         .def_property_readonly("dyn", &sim::get_dyn)
         .def_property_readonly("device", &sim::get_device)
         .def_property("host_sync", &sim::get_host_sync, &sim::set_host_sync)

@@ -578,6 +578,12 @@ sim::sim(const sim &o)
       m_coll_whitelist(o.m_coll_whitelist), m_conj_whitelist(o.m_conj_whitelist),
       m_data(std::make_unique<sim_data>(*o.m_data))
 {
+    // With host_sync off the device copy of the source is the authoritative one and its host
+    // vector may be stale: the copy takes the coordinates from the device.
+    const auto &od = *o.m_data;
+    if (!od.host_sync && od.ctx != nullptr && od.dev_rows == static_cast<std::int64_t>(o.get_nparts()) && o.get_nparts() != 0u) {
+        od.chk(csc_download(od.ctx, m_state->data(), od.bufs.at("state").p, m_state->size() * sizeof(double), nullptr));
+    }
 }
 
 sim::sim(sim &&) noexcept = default;
@@ -1204,6 +1210,10 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
 
     d.state_prestep = true;
+    // (the view points into the context's pinned buffer, which the narrow phase below may free)
+    d.last_conj_view = nullptr;
+    d.last_conj_n = 0;
+    d.last_conj.clear();
     const std::size_t cn = static_cast<std::size_t>(nchunks0) * n;
     double *d_state = d.buf<double>("state", n * 7ull);
     auto *d_active = d.buf<std::uint8_t>("active", n);

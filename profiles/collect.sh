@@ -12,9 +12,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo "stats pass done"
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/fetch.json 2> $OUT/fetch.log
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-sync-leg > $OUT/fetch.json 2> $OUT/fetch.log
 echo "fetch pass done"
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/write.json 2> $OUT/write.log
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-sync-leg > $OUT/write.json 2> $OUT/write.log
 echo "write pass done"
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "plain bench done"

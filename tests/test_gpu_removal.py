@@ -130,3 +130,25 @@ def test_new_state_after_resident_steps_is_uploaded():
     c.step()
     c.host_sync = True
     assert np.array_equal(np.array(c.state), np.array(b.state))
+
+
+def test_copy_of_a_resident_simulation_takes_the_device_state():
+    """A copy made while the state is resident on the device (host_sync off, host vector stale)
+    must hold the current state, not the one of the last download."""
+    import copy
+
+    from cascade_amd import sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(3000, seed=3)
+    a = sim(st.copy(), 0.23)
+    a.host_sync = False
+    for _ in range(3):
+        a.step()
+    b = copy.copy(a)
+    a.download_state()
+    assert np.array_equal(np.array(a.state), np.array(b.state)) and a.time == b.time
+    assert a.step() == b.step()
+    a.download_state()
+    b.download_state()
+    assert np.array_equal(np.array(a.state), np.array(b.state))
