@@ -86,6 +86,7 @@ struct csc_ctx {
     const uint32_t *bp_vidx = nullptr; // the permutation the pair positions refer to
     uint32_t bp_n = 0, bp_chunks = 0;
     uint32_t shard_rank = 0, shard_n = 1; // query sharding of the broad phase (csc_set_shard)
+    uint32_t chunk_first = 0, chunk_global = 0; // csc_set_chunk_map: the narrow phase's chunk c is chunk chunk_first + c of chunk_global
     // dual traversal (k_bp_dual.hpp): flat pair lists of the last broad phase, capacities that
     // follow the last superstep
     bool bp_flat = false;
@@ -1570,6 +1571,13 @@ uint64_t csc_broad_phase_node_pairs(csc_ctx *ctx)
     return ctx->bp_node_pairs;
 }
 
+int csc_set_chunk_map(csc_ctx *ctx, uint32_t first, uint32_t nchunks_global)
+{
+    ctx->chunk_first = nchunks_global ? first : 0u;
+    ctx->chunk_global = nchunks_global;
+    return CSC_OK;
+}
+
 int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
 {
     if (nranks == 0u || rank >= nranks) {
@@ -2025,6 +2033,8 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         csc::np_params q{};
         q.n = n;
         q.nchunks = nchunks;
+        q.chunk_first = ctx->chunk_first;
+        q.nchunks_global = ctx->chunk_global ? ctx->chunk_global : nchunks;
         q.ct = ct;
         q.delta_t = delta_t;
         q.init_hi = init_time_hi;

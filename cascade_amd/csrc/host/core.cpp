@@ -333,7 +333,7 @@ PYBIND11_MODULE(core, m)
             "rank"_a, "nranks"_a, "exchange"_a = py::none{})
         .def(
             "set_shard_propagation",
-            [](sim &s, py::object gather) {
+            [](sim &s, py::object gather, bool chunks) {
                 // gather(send_address, recv_address, nbytes): all-gather of device memory.
                 sim::gather_t fn;
                 if (!gather.is_none()) {
@@ -342,9 +342,10 @@ PYBIND11_MODULE(core, m)
                         gather(send, recv, bytes);
                     };
                 }
-                s.set_shard_propagation(std::move(fn));
+                s.set_shard_propagation(std::move(fn), chunks);
             },
-            "gather"_a = py::none{})
+            "gather"_a = py::none{}, "chunks"_a = true)
+        .def_property_readonly("last_chunk_block", [](const sim &s) { return std::make_pair(s.get_step_stats().chunk_first, s.get_step_stats().chunk_count); })
         .def_property_readonly("_conj_segments",
                                [](const sim &s) {
                                    const auto &v = s._get_conj_segments();

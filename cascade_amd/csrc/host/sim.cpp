@@ -437,6 +437,8 @@ struct sim::sim_data {
     std::uint32_t shard_rank = 0, shard_n = 1;
     exchange_t exchange;
     gather_t gather; // propagation sharded too when set
+    bool shard_chunks = true;                 // ... and, with n_par_ct >= nranks, the chunks dealt to the processes
+    std::uint32_t chunk_c0 = 0, chunk_cl = 0; // chunk block of the last step on this process
     // Hashes of the host state / parameter vectors as of the last transfer (csc_upload /
     // csc_download): when they still match at the next step(), the caller has not edited the
     // arrays and the device copies are current.
@@ -463,7 +465,7 @@ struct sim::sim_data {
         : dyn(o.dyn), tape(o.tape), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
           single_pass_mode(o.single_pass_mode),
-          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather)
+          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather), shard_chunks(o.shard_chunks)
     {
     }
     ~sim_data()
@@ -964,9 +966,10 @@ void sim::set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchang
     m_data->exchange = std::move(exchange);
 }
 
-void sim::set_shard_propagation(gather_t gather)
+void sim::set_shard_propagation(gather_t gather, bool chunks)
 {
     m_data->gather = std::move(gather);
+    m_data->shard_chunks = chunks;
 }
 
 void sim::set_np_prefilter(bool v)
@@ -1097,7 +1100,9 @@ void sim::dense_propagate(double t)
         std::uint32_t xs = 0, vs = 0;
         d.chk(csc_tc_strides(d.order, &xs, &vs));
         const std::uint64_t tot = std::max<std::uint64_t>(d.stats.total_substeps, 1);
-        d.chk(csc_propagate_store(d.ctx, &d.last_cfg, n, d.get<double>("state"), d.get<std::uint32_t>("vidx"),
+        // (row order: the Morton order of this process's first chunk, when it has one)
+        const std::uint32_t *order = d.chunk_cl != 0u ? d.get<std::uint32_t>("vidx") + static_cast<std::size_t>(d.chunk_c0) * n : nullptr;
+        d.chk(csc_propagate_store(d.ctx, &d.last_cfg, n, d.get<double>("state"), order,
                                   d.get<std::uint32_t>("nsub"), d.get<std::uint64_t>("tc_row"), d.buf<double>("tcs_xyz", tot * xs),
                                   d.buf<double>("tcs_vr", tot * vs), d.buf<double>("tcoords", tot * 2u)));
         d.rows_full = true;
@@ -1390,10 +1395,43 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         nchunks = std::min(new_nchunks, nchunks0);
     }
 
+    // Chunks are independent once the trajectories are known (doc/collision_algorithm.rst:71-80):
+    // with the propagation sharded and at least one chunk per process, every process sorts, builds
+    // the tree of, traverses and narrow-phases ITS block of chunks [c0, c0 + cl) only -- nothing
+    // but the integration's all-gather is shared, nothing is replicated. (Otherwise: all chunks
+    // here, the pair tree of every chunk sharded over the processes.)
+    const bool chunk_mode = shard_prop && d.shard_chunks && nchunks0 >= d.shard_n;
+    std::uint32_t c0 = 0, cl = nchunks;
+    if (chunk_mode) {
+        const std::uint32_t per_c = (nchunks0 + d.shard_n - 1u) / d.shard_n;
+        c0 = std::min(nchunks, d.shard_rank * per_c);
+        cl = std::min(per_c, nchunks - c0);
+        const std::size_t o = static_cast<std::size_t>(c0) * n;
+        d_lbs += o * 4u;
+        d_ubs += o * 4u;
+        d_glb += c0 * 4ull;
+        d_gub += c0 * 4ull;
+        d_codes += o;
+        d_vidx += o;
+        d_scodes += o;
+        d_slbs += o * 4u;
+        d_subs += o * 4u;
+        if (d_recs != nullptr) {
+            d_recs += o * 16u;
+            d_srecs += o * 16u;
+        }
+    }
+    d.chunk_c0 = c0;
+    d.chunk_cl = cl;
+    d.chk(csc_set_chunk_map(ctx, c0, chunk_mode ? nchunks : 0u));
+    const bool have_chunks = cl != 0u;
+
     sw = stopwatch{};
-    d.chk(csc_global_aabb(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub));
-    d.chk(csc_morton_encode(ctx, n, nchunks, d_lbs, d_ubs, d_glb, d_gub, d_codes));
-    d.chk(csc_sort_gather(ctx, n, nchunks, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs));
+    if (have_chunks) {
+        d.chk(csc_global_aabb(ctx, n, cl, d_lbs, d_ubs, d_glb, d_gub));
+        d.chk(csc_morton_encode(ctx, n, cl, d_lbs, d_ubs, d_glb, d_gub, d_codes));
+        d.chk(csc_sort_gather(ctx, n, cl, d_codes, d_lbs, d_ubs, d_vidx, d_scodes, d_slbs, d_subs, d_recs, d_srecs));
+    }
 
     if (tracing) {
         d.chk(csc_sync(ctx));
@@ -1402,20 +1440,28 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     const std::uint64_t tot = summ.total_substeps;
     d.last_cfg = cfg;
-    d.chk(csc_bvh_build(ctx, n, nchunks, d_scodes, d_slbs, d_subs));
+    if (have_chunks) {
+        d.chk(csc_bvh_build(ctx, n, cl, d_scodes, d_slbs, d_subs));
+    }
     if (tracing) {
         d.chk(csc_sync(ctx));
         log_line(LOG_TRACE, "BVH construction time: " + sw.elapsed() + "s");
         sw = stopwatch{};
     }
     std::uint64_t npairs = 0;
-    d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));
-    d.chk(csc_broad_phase(ctx, n, nchunks, d_slbs, d_subs, d_vidx, d_active, &npairs));
+    if (chunk_mode) {
+        d.chk(csc_set_shard(ctx, 0u, 1u));
+    } else {
+        d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));
+    }
+    if (have_chunks) {
+        d.chk(csc_broad_phase(ctx, n, cl, d_slbs, d_subs, d_vidx, d_active, &npairs));
+    }
     if (tracing) {
         // src/sim_broad_phase.cpp:209-213 (with a sharded simulation: this process's share)
         log_line(LOG_TRACE, "Broad phase collision detection time: " + sw.elapsed() + "s");
         log_line(LOG_TRACE, "Average number of AABB collisions per particle per chunk: "
-                                + fmt_d(static_cast<double>(npairs) / static_cast<double>(nchunks) / static_cast<double>(n)));
+                                + fmt_d(static_cast<double>(npairs) / static_cast<double>(std::max(cl, 1u)) / static_cast<double>(n)));
         sw = stopwatch{};
     }
     {
@@ -1436,14 +1482,17 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         d_txyz = d.buf<double>("tcs_xyz", std::max<std::uint64_t>(tot, 1) * xs);
         d_tvr = d.buf<double>("tcs_vr", std::max<std::uint64_t>(tot, 1) * vs);
         d_tco = d.buf<double>("tcoords", std::max<std::uint64_t>(tot, 1) * 2u);
-        d.chk(csc_propagate_store(ctx, &cfg, n, d_state, d_vidx, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
+        d.chk(csc_propagate_store(ctx, &cfg, n, d_state, have_chunks ? d_vidx : nullptr, d_nsub, d_tc_row, d_txyz, d_tvr, d_tco));
         d.rows_full = true;
         d.stats.stored_objects = n;
     };
-    if (sparse) {
+    if (!have_chunks) {
+        // (a terminal event cut the superstep short of this process's chunks: nothing to look for)
+        d.rows_full = false;
+    } else if (sparse) {
         std::uint64_t ncand = 0, nrows = 0;
         std::uint32_t nlist = 0;
-        d.chk(csc_narrow_phase_prefilter(ctx, n, nchunks, m_conj_thresh, d_srecs, &ncand));
+        d.chk(csc_narrow_phase_prefilter(ctx, n, cl, m_conj_thresh, d_srecs, &ncand));
         np_attempts += csc_narrow_phase_attempts(ctx) - 1u;
         auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
         d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, nullptr));
@@ -1462,7 +1511,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
             }
             d.rows_full = false;
         }
-        d.chk(csc_narrow_phase_finish(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state,
+        d.chk(csc_narrow_phase_finish(ctx, n, cl, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state,
                                       d_active, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, &ncoll, &nconj, &warn));
     } else {
         if (!rows_done) {
@@ -1470,10 +1519,10 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         } else {
             d.rows_full = true;
         }
-        d.chk(csc_narrow_phase(ctx, n, nchunks, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
+        d.chk(csc_narrow_phase(ctx, n, cl, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
                                d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
     }
-    if (!rows_done) {
+    if (!rows_done && have_chunks) {
         // A second integration pass wrote the rows: it must have repeated the substep counts of the
         // first one (csc_propagate_store never writes past a particle's rows and reports a mismatch).
         d.chk(csc_check_flags(ctx));
@@ -1483,7 +1532,9 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     const csc_collision *coll_p = nullptr;
     const csc_conjunction *conj_p = nullptr;
     std::uint64_t ncoll_v = 0, nconj_v = 0;
-    d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
+    if (have_chunks) {
+        d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
+    }
     pt.lap("narrow");
     if (tracing) {
         // src/sim_narrow_phase.cpp:1017-1021
@@ -1501,9 +1552,11 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
 
     d.stats.bp_pairs = npairs;
-    d.stats.bp_node_pairs = csc_broad_phase_node_pairs(ctx);
-    d.stats.np_candidates = csc_narrow_phase_candidates(ctx);
-    d.stats.np_attempts = np_attempts + csc_narrow_phase_attempts(ctx);
+    d.stats.bp_node_pairs = have_chunks ? csc_broad_phase_node_pairs(ctx) : 0u;
+    d.stats.np_candidates = have_chunks ? csc_narrow_phase_candidates(ctx) : 0u;
+    d.stats.np_attempts = have_chunks ? np_attempts + csc_narrow_phase_attempts(ctx) : 0u;
+    d.stats.chunk_first = c0;
+    d.stats.chunk_count = cl;
     d.stats.total_substeps = tot;
     d.stats.nchunks = nchunks;
     d.last_coll.clear();
@@ -1515,7 +1568,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     d.last_conj_view = conj_p;
     d.last_conj_n = nconj_v;
     std::vector<csc_collision> coll(coll_p, coll_p + ncoll_v);
-    std::uint64_t ncand_all = csc_narrow_phase_candidates(ctx);
+    std::uint64_t ncand_all = d.stats.np_candidates;
     if (d.shard_n > 1u) {
         // One 48-byte summary per process: the outcome logic below needs the earliest collision
         // of all processes (coll is sorted by (time, i, j)); the conjunction records stay here.

@@ -48,6 +48,9 @@ constexpr unsigned NP_FLAT_TILE = 256; // pairs per workgroup of k_np_prefilter_
 struct np_params {
     std::uint32_t n;       // particles
     std::uint32_t nchunks; // chunks (after a possible STE shrink)
+    // The chunks may be a block of a longer superstep (chunks dealt to several GPUs): chunk c here
+    // is chunk chunk_first + c of nchunks_global, which is what its time window follows.
+    std::uint32_t chunk_first, nchunks_global;
     double ct, delta_t;    // delta_t after a possible STE shrink (src/sim_narrow_phase.cpp:560)
     double init_hi, init_lo;
     double conj_thresh2;
@@ -471,12 +474,13 @@ CSC_DEV void np_build_ss(double *ss, const double *xyz, std::uint64_t row_i, std
 
 CSC_DEV dfl np_chunk_begin(const np_params &q, std::uint32_t c)
 {
-    return df(q.ct * static_cast<double>(c));
+    return df(q.ct * static_cast<double>(q.chunk_first + c));
 }
 // get_chunk_begin_end (src/sim_basic.cpp:87-103)
 CSC_DEV dfl np_chunk_end(const np_params &q, std::uint32_t c)
 {
-    return df((c == q.nchunks - 1u) ? q.delta_t : q.ct * static_cast<double>(c + 1u));
+    const std::uint32_t g = q.chunk_first + c;
+    return df((g == q.nchunks_global - 1u) ? q.delta_t : q.ct * static_cast<double>(g + 1u));
 }
 
 // The fast exclusion checks on one window, given its distance-square polynomial (clobbered).

@@ -8,10 +8,13 @@ Every process holds the same simulation (same state, same calls). Per superstep
   2. ONE all-gather of the per-particle records -- substep count, status, event, final state and,
      per chunk, the box and the 64-byte trajectory record: 80 + 96 C bytes -- in place on the
      simulation's device buffers (``make_device_gather``);
-  3. every process sorts the Morton codes and builds the whole tree (replicated: cheaper than a
-     distributed sort at these sizes, and it makes the tree bit-identical everywhere), expands
-     only its share of the pair tree and runs the narrow phase on the pairs it found; Taylor rows
-     are produced on demand for the particles of its candidate pairs;
+  3. with ``n_par_ct >= world`` every process owns a block of the superstep's chunks -- chunks
+     are independent once the trajectories are known -- and sorts, builds the trees of, traverses
+     and narrow-phases only those: nothing is replicated. With fewer chunks than processes every
+     process sorts and builds the whole tree of every chunk (replicated: cheaper than a distributed
+     sort at these sizes, and bit-identical everywhere), expands only its share of each pair tree
+     and runs the narrow phase on the pairs it found. Either way Taylor rows are produced on demand
+     for the particles of the local candidate pairs;
   4. ONE all-gather of a 48-byte summary per process (``make_summary_exchange``: event counts
      and the earliest local collision), from which every process derives the same outcome.
 
@@ -73,16 +76,19 @@ def make_device_gather(group=None):
     return gather
 
 
-def shard(sim_obj, group=None, propagation=True):
+def shard(sim_obj, group=None, propagation=True, chunks=True):
     """Shard ``sim_obj`` over the processes of ``group`` (call it on every process, on
     simulations constructed from the same arguments). ``propagation=False`` keeps the integration
-    replicated on every process (no all-gather of the per-particle records)."""
+    replicated on every process (no all-gather of the per-particle records). ``chunks`` (with
+    the propagation sharded and ``n_par_ct >= world``): every process also owns a block of the
+    superstep's chunks and sorts / builds / traverses / narrow-phases only those -- nothing is
+    replicated; ``chunks=False`` keeps every chunk on every process with its pair tree sharded."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if world > 1:
         sim_obj.set_shard(rank, world, make_summary_exchange(group))
-        sim_obj.set_shard_propagation(make_device_gather(group) if propagation else None)
+        sim_obj.set_shard_propagation(make_device_gather(group) if propagation else None, chunks)
     return sim_obj
 
 

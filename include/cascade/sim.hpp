@@ -212,6 +212,7 @@ public:
         std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles
         std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)
+        std::uint32_t chunk_first = 0, chunk_count = 0; // the block of them this process handled (all, unless the chunks are sharded)
         std::uint64_t stored_objects = 0; // particles whose Taylor rows were written (all, or those of the candidate pairs)
         std::uint32_t np_attempts = 0;    // narrow-phase passes (more than one per call: an output list overflowed and was grown)
     };
@@ -407,7 +408,10 @@ public:
     // there. Pays when the integration dominates the superstep (expensive right-hand sides,
     // many chunks); for 1M Kepler objects the replicated integration is cheaper than the gather.
     using gather_t = std::function<void(std::uintptr_t, std::uintptr_t, std::size_t)>;
-    void set_shard_propagation(gather_t gather);
+    // chunks (default on): with n_par_ct >= nranks each process then also owns a block of the
+    // n_par_ct chunks -- it sorts, builds, traverses and narrow-phases those chunks only (chunks are
+    // independent once the trajectories are known), so nothing of the superstep is replicated.
+    void set_shard_propagation(gather_t gather, bool chunks = true);
     // Geometric pre-filter in front of the polynomial narrow phase (on by default; it never
     // changes the detected events, see k_np_prefilter).
     void set_np_prefilter(bool);

@@ -311,6 +311,12 @@ uint64_t csc_broad_phase_node_pairs(csc_ctx *ctx);
  * union over the processes is the full pair set. The narrow phase then works on the local
  * pairs. Default (0, 1). */
 int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks);
+/* Multi-GPU chunk sharding (no counterpart in the reference; its chunks are an outer loop of one
+ * process, src/sim_propagate.cpp:533-538): the chunk arrays handed to the stages may be a block
+ * [first, first + nchunks) of a superstep of nchunks_global chunks. Sort, tree and traversal do
+ * not care; the narrow phase derives each chunk's time window (get_chunk_begin_end,
+ * src/sim_basic.cpp:87-103) from the global index. nchunks_global = 0 (default): no mapping. */
+int csc_set_chunk_map(csc_ctx *ctx, uint32_t first, uint32_t nchunks_global);
 /* Diagnostic (measurement only): re-runs the traversal of the last csc_broad_phase without
  * writing pairs and returns the number of node AABB tests, i.e. the reference's "nodes
  * visited" (every node popped from the stack of src/sim_broad_phase.cpp:121-196), summed over

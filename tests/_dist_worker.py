@@ -110,6 +110,8 @@ def main():
         # the unsharded simulation: plain Kepler with collisions and conjunctions, and J2 + drag
         # with reentries and removals; ragged ranges (the particle counts are no multiples of the
         # number of processes).
+        import torch
+
         from cascade_amd import dynamics, outcome, sim
         from cascade_amd.parallel import gather_conjunctions, shard
         from cascade_amd.workloads import leo_si_population, random_leo_pop_kep
@@ -120,24 +122,36 @@ def main():
             c = np.concatenate(objs)
             return c[np.lexsort((c["j"], c["i"], c["time"]))]
 
-        st = random_leo_pop_kep(6001, seed=21)
-        st[:, 6] *= 3e4
-        full = sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=1e-3, device=dev)
-        part = shard(sim(st.copy(), 0.23, n_par_ct=3, conj_thresh=1e-3, device=dev), propagation=True)
-        events = 0
-        for _ in range(4):
-            of, op = full.step(), part.step()
-            assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
-            assert np.array_equal(full.state, part.state)
-            assert full.time == part.time
-            assert all_collisions(part).tobytes() == full.last_collisions.tobytes()
-            per = -(-6001 // world)
-            assert full.last_propagated == 6001 and part.last_propagated == min(per, 6001 - rank * per)
-            events += len(full.last_collisions) + len(full.last_step_conjunctions)
-        of, op = full.propagate_until(full.time + 1.0), part.propagate_until(part.time + 1.0)
-        assert of == op and full.time == part.time and np.array_equal(full.state, part.state)
-        assert gather_conjunctions(part).tobytes() == full.conjunctions.tobytes()
-        assert events > 0
+        # (a) chunks dealt to the processes (n_par_ct = 3 and 7: even and ragged blocks), (b) every
+        # chunk everywhere with its pair tree sharded.
+        for n_par_ct, chunks in [(3, True), (7, True), (3, False)]:
+            st = random_leo_pop_kep(6001, seed=21)
+            st[:, 6] *= 3e4
+            full = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=1e-3, device=dev)
+            part = shard(sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=1e-3, device=dev), propagation=True, chunks=chunks)
+            events = 0
+            for _ in range(4):
+                of, op = full.step(), part.step()
+                assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
+                assert np.array_equal(full.state, part.state)
+                assert full.time == part.time
+                assert all_collisions(part).tobytes() == full.last_collisions.tobytes()
+                per = -(-6001 // world)
+                assert full.last_propagated == 6001 and part.last_propagated == min(per, 6001 - rank * per)
+                t = torch.tensor([part.last_bp_pairs], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t)
+                assert int(t.item()) == full.last_bp_pairs, (int(t.item()), full.last_bp_pairs)
+                c0, cl = part.last_chunk_block
+                if chunks and of.name == "success":
+                    per_c = -(-n_par_ct // world)
+                    assert (c0, cl) == (min(n_par_ct, rank * per_c), max(0, min(per_c, n_par_ct - rank * per_c))), (rank, c0, cl)
+                elif not chunks:
+                    assert c0 == 0 and cl == full.last_nchunks
+                events += len(full.last_collisions) + len(full.last_step_conjunctions)
+            of, op = full.propagate_until(full.time + 1.0), part.propagate_until(part.time + 1.0)
+            assert of == op and full.time == part.time and np.array_equal(full.state, part.state)
+            assert gather_conjunctions(part).tobytes() == full.conjunctions.tobytes()
+            assert events > 0
 
         Re, GM = 6378136.3, 3.986004407799724e14
         st, pars = leo_si_population(1003, seed=7)
