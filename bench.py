@@ -2,19 +2,24 @@
 """bench.py -- object-days propagated per second, collision detection included.
 
 Workload (BASELINE.json configs[1]): the random LEO Kepler population of
-benchmark/random_leo_pop_kep.cpp scaled to 1,000,000 objects, ct = 0.23, n_par_ct = 1, Keplerian
-dynamics mu = 1 (1 TU = 806.81 s). A "step" is one sim.step() (propagate -> AABB -> Morton ->
-sort -> BVH -> broad phase -> narrow phase -> outcome) with the state already resident in HBM.
+benchmark/random_leo_pop_kep.cpp scaled to 1,000,000 objects, ct = 0.23, Keplerian dynamics
+mu = 1 (1 TU = 806.81 s), n_par_ct = 8 collisional timesteps per superstep (SURVEY 8(d) config 2
+lists C in {1, 8}; results do not depend on it; 8 is what lets 8 GPUs take one chunk each, and it
+is the faster setting on one GPU too; the C = 1 figure of round 1 is reported beside it as
+"n_par_ct_1"). A "step" is one sim.step() (propagate -> AABB -> Morton -> sort -> BVH -> broad
+phase -> narrow phase -> outcome over the 8 chunks) with the state already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 ONE experiment at every N: one 1M-object simulation (strong scaling). At N > 1 it is sharded the
 way BASELINE.json's north_star says: every rank integrates its own range of objects, one RCCL
-all-gather moves the per-object records (boxes, trajectory records, final states), every rank
-sorts and builds the tree, expands its share of the pair tree and runs the narrow phase on its
-pairs; conjunction records stay on the rank that found them, collisions and the earliest event are
-exchanged (cascade_amd/parallel.py). --replicate-propagation keeps the
+exchange moves the per-object records (final states; per-chunk boxes and trajectory records);
+every rank takes its block of the superstep's chunks -- chunks are independent -- and sorts,
+builds the trees of, traverses and narrow-phases those only, so the exchange is an all-to-all
+that brings a rank the per-chunk records of its own chunks (with fewer chunks than ranks: an
+all-gather, every chunk everywhere, pair trees sharded); conjunction records stay on the rank that found them,
+event counts and the earliest collision are exchanged (cascade_amd/parallel.py). --replicate-propagation keeps the
 integration on every rank instead; --mode replicas runs N independent simulations (weak scaling,
 no collective; not the default).
 
@@ -81,7 +86,10 @@ BYTES = {
     "k_broad_phase": lambda u: u["bp_nodes_visited"] * 44 + u["pairs"] * 8,
     # K6 = 44 B x nodes visited + 8 B x pairs; the dual traversal visits two nodes per node pair.
     "k_bp_dual": lambda u: u["bp_node_pairs"] * 2 * 44 + u["pairs"] * 8,
-    "k_np_prefilter": lambda u: u["pairs"] * (8 + 128),
+    # single-pass rows (every object's substep rows written while it is integrated)
+    "k_propagate_rows": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28 + 64 * u["nchunks"]) + u["substeps"] * (1176 + 16),
+    # every pair record read once, every trajectory record read once (the pairs of a chunk share them)
+    "k_np_prefilter": lambda u: u["pairs"] * 8 + u["n"] * u["nchunks"] * 64,
     "k_rs_scatter": lambda u: u["sort_keys"] * 24,
     "k_rs_hist": lambda u: u["sort_keys"] * 8,
     "k_gather_aabb": lambda u: u["n"] * u["nchunks"] * 2 * (32 + 64),
@@ -112,7 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nparts", type=int, default=1_000_000)
     ap.add_argument("--ct", type=float, default=0.23)
-    ap.add_argument("--n-par-ct", type=int, default=1)
+    ap.add_argument("--n-par-ct", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-sync-leg", action="store_true")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded")
@@ -266,7 +274,7 @@ def main():
             alg_bytes = BYTES[name](units) / per_step_launches
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             r.update(achieved=round(achieved, 2), frac=round(achieved / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(alg_bytes))
-        if name == "k_propagate":
+        if name in ("k_propagate", "k_propagate_rows"):
             # report against the FP64 vector peak AND the HBM figure; the bound that
             # takes longer at its peak is the binding one.
             fl = taylor_flops("kepler") * units["substeps"] / per_step_launches
@@ -290,7 +298,10 @@ def main():
     elif world == 1:
         parallelism = "one simulation, one GPU"
     elif shard_prop:
-        parallelism = "one simulation: propagation sharded x%d, one RCCL all-gather of the per-object records, replicated sort / BVH, pair tree and narrow phase sharded x%d, conjunction records rank-local, collisions + earliest event exchanged" % (world, world)
+        if args.n_par_ct >= world:
+            parallelism = "one simulation: propagation sharded x%d, the %d chunks dealt to the ranks (sort / BVH / broad / narrow phase of a rank's chunks only: nothing replicated), one RCCL all-to-all brings each rank the per-object records of its chunks, conjunction records rank-local, event counts + earliest collision exchanged" % (world, args.n_par_ct)
+        else:
+            parallelism = "one simulation: propagation sharded x%d, one RCCL all-gather of the per-object records, replicated sort / BVH, pair tree and narrow phase sharded x%d, conjunction records rank-local, event counts + earliest collision exchanged" % (world, world)
     else:
         parallelism = "one simulation: replicated propagation / sort / BVH, pair tree and narrow phase sharded x%d, conjunction records rank-local, collisions + earliest event exchanged" % world
 
@@ -316,6 +327,7 @@ def main():
             "backend": backend,
             "ranks": world,
             "propagated_per_rank": per_rank_prop,
+            "exchange_bytes_received_per_step_rank0": int(s.last_exchanged_bytes),
             "bp_pairs_per_step_per_rank": per_rank_pairs,
             "bp_pairs_per_step_all_ranks": pairs_all,
             "outcomes": outcomes,
@@ -343,6 +355,22 @@ def main():
         out["ms_per_step_host_sync"] = round((time.perf_counter() - t1) / k * 1e3, 4)
         s.host_sync = False
 
+    if world == 1 and not args.no_host_sync_leg and args.n_par_ct != 1:
+        # Round 1's configuration (n_par_ct = 1) on the same population, for continuity.
+        c1 = sim(st, args.ct, n_par_ct=1, device=local_rank)
+        c1.host_sync = False
+        for _ in range(3):
+            c1.step()
+        c1x = _capi.Context.from_handle(c1._hip_context)
+        c1x.sync()
+        t1, ts1, k1 = time.perf_counter(), c1.time, 10
+        for _ in range(k1):
+            c1.step()
+        c1x.sync()
+        w1 = time.perf_counter() - t1
+        out["n_par_ct_1"] = {"ms_per_step": round(w1 / k1 * 1e3, 4), "value": round(N * (c1.time - ts1) * TU_SECONDS / 86400.0 / w1, 2), "unit": "object-days/s", "steps": k1}
+        del c1
+
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, st_w, t_w, pairs_by_step)
 
@@ -362,7 +390,7 @@ def cpu_baseline(args, st_w, t_w, gpu_pairs_by_step):
 
     orc_py.build()
     n = len(st_w)
-    nsteps = 3
+    nsteps = 3 if args.n_par_ct < 4 else 2  # (about 2.2 s of CPU per chunk of 1M objects on 16 threads)
     g = sim(st_w.copy(), args.ct, n_par_ct=args.n_par_ct)
     g.time = t_w
     o = orc_py.Sim(st_w.copy(), args.ct, n_par_ct=args.n_par_ct)
@@ -394,7 +422,7 @@ def cpu_baseline(args, st_w, t_w, gpu_pairs_by_step):
         "unit": "object-days/s",
         "cores": int(orc_py.lib().orc_num_threads()),
         "kind": "port",
-        "sample": "supersteps 1-3 of the timed region from the same state (%d objects, ct=%g x n_par_ct=%d): 1 untimed + 2 timed, %.3f s of CPU wall" % (n, args.ct, args.n_par_ct, wall),
+        "sample": "supersteps 1-%d of the timed region from the same state (%d objects, ct=%g x n_par_ct=%d): 1 untimed + %d timed, %.3f s of CPU wall" % (nsteps, n, args.ct, args.n_par_ct, nsteps - 1, wall),
         "checked_against_gpu": checked,
         "check": "outcome, broad-phase pair count, collision and conjunction lists equal; states within 1e-9 relative",
         "stage_times_last_step_s": o.stage_times(),

@@ -131,6 +131,9 @@ SYMBOLS = {
     "csc_shard_record_bytes": (_sz, [_u32]),
     "csc_shard_pack": (_i32, [_vp, _u32, _u32, _u32, _u32] + [_vp] * 10),
     "csc_shard_unpack": (_i32, [_vp, _u32, _u32] + [_vp] * 10),
+    "csc_shard_block": (_i32, [_u32, _u32, _u32, _vp, _vp]),
+    "csc_shard_pack_blocks": (_i32, [_vp, _u32, _u32, _u32, _u32, _u32, _u32] + [_vp] * 10),
+    "csc_shard_unpack_block": (_i32, [_vp, _u32, _u32, _u32, _u32] + [_vp] * 10),
     "csc_narrow_phase_prefilter": (_i32, [_vp, _u32, _u32, _dbl, _vp, C.POINTER(_u64)]),
     "csc_candidate_objects": (_i32, [_vp, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_u64)]),
     "csc_narrow_phase_finish": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 7 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),

@@ -371,21 +371,38 @@ __host__ __device__ inline size_t shard_record_bytes(uint32_t nchunks)
     return 80u + 96u * static_cast<size_t>(nchunks);
 }
 
-// UNPACK = false: particle first + k -> record k of buf; true: record k of buf -> particle
-// (k / per_rank) * per_rank + k % per_rank = k, for the records that hold a particle (k < n).
+// The block of chunks a process owns when the chunks are dealt out (csc_shard_block): blocks of
+// per_c = ceil(nchunks / nranks) consecutive chunks, in rank order, until the chunks run out.
+__host__ __device__ inline void shard_block(uint32_t nchunks, uint32_t per_c, uint32_t rank, uint32_t &cb, uint32_t &ce)
+{
+    const uint64_t b = static_cast<uint64_t>(rank) * per_c;
+    cb = b < nchunks ? static_cast<uint32_t>(b) : nchunks;
+    ce = nchunks - cb < per_c ? nchunks : cb + per_c;
+}
+
+// UNPACK = false: particle first + k -> record k of segment blockIdx.y of buf; segment y holds
+// records with the chunks of block y only (per slots each; one segment with every chunk when
+// per_c = nchunks: the all-gather form). UNPACK = true: record k of buf, which holds the chunks
+// [cb_u, ce_u) -> particle first + k (equal segments of per records in rank order: record k is
+// particle k).
 template <bool UNPACK>
-__global__ __launch_bounds__(256) void k_shard_records(uint32_t first, uint32_t count, uint32_t n, uint32_t nchunks, shard_arrays a,
-                                                       unsigned char *buf)
+__global__ __launch_bounds__(256) void k_shard_records(uint32_t first, uint32_t count, uint32_t n, uint32_t per, uint32_t nchunks,
+                                                       uint32_t per_c, uint32_t cb_u, uint32_t ce_u, shard_arrays a, unsigned char *buf)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) {
         return;
     }
     const uint32_t i = first + k;
-    unsigned char *rec = buf + static_cast<size_t>(k) * shard_record_bytes(nchunks);
+    uint32_t cb = cb_u, ce = ce_u;
+    if constexpr (!UNPACK) {
+        shard_block(nchunks, per_c, blockIdx.y, cb, ce);
+        buf += static_cast<size_t>(per) * (80u * static_cast<size_t>(blockIdx.y) + 96u * static_cast<size_t>(cb));
+    }
+    unsigned char *rec = buf + static_cast<size_t>(k) * shard_record_bytes(ce - cb);
     uint32_t *r32 = reinterpret_cast<uint32_t *>(rec);
     double *r64 = reinterpret_cast<double *>(rec);
-    float4 *rf4 = reinterpret_cast<float4 *>(rec + 80);
+    float4 *rf4 = reinterpret_cast<float4 *>(rec + 80) - static_cast<size_t>(cb) * 6u; // indexed by the chunk's own number below
     if constexpr (!UNPACK) {
         r32[0] = a.nsub[i];
         r32[1] = static_cast<uint32_t>(a.status[i]);
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(256) void k_shard_records(uint32_t first, uint32_t 
         for (int j = 0; j < 6; ++j) {
             r64[4 + j] = a.final_state[static_cast<size_t>(i) * 6u + j];
         }
-        for (uint32_t c = 0; c < nchunks; ++c) {
+        for (uint32_t c = cb; c < ce; ++c) {
             const size_t e = static_cast<size_t>(c) * n + i;
             rf4[c * 6u] = a.lbs[e];
             rf4[c * 6u + 1u] = a.ubs[e];
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256) void k_shard_records(uint32_t first, uint32_t 
         for (int j = 0; j < 6; ++j) {
             a.final_state[static_cast<size_t>(i) * 6u + j] = r64[4 + j];
         }
-        for (uint32_t c = 0; c < nchunks; ++c) {
+        for (uint32_t c = cb; c < ce; ++c) {
             const size_t e = static_cast<size_t>(c) * n + i;
             a.lbs[e] = rf4[c * 6u];
             a.ubs[e] = rf4[c * 6u + 1u];
@@ -1192,7 +1209,63 @@ int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uin
                    reinterpret_cast<float4 *>(const_cast<float *>(d_lbs)), reinterpret_cast<float4 *>(const_cast<float *>(d_ubs)),
                    reinterpret_cast<float4 *>(const_cast<float *>(d_recs))};
     KT("k_shard_pack", hipLaunchKernelGGL((k_shard_records<false>), dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, first, count, n,
-                                           nchunks, a, static_cast<unsigned char *>(d_records)));
+                                           count, nchunks, nchunks, 0u, 0u, a, static_cast<unsigned char *>(d_records)));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_shard_block(uint32_t nchunks, uint32_t nranks, uint32_t rank, uint32_t *first, uint32_t *count)
+{
+    if (nranks == 0u) {
+        return CSC_ERR_INVALID;
+    }
+    uint32_t cb = 0, ce = 0;
+    shard_block(nchunks, cdiv(nchunks, nranks), rank, cb, ce);
+    *first = cb;
+    *count = ce - cb;
+    return CSC_OK;
+}
+
+int csc_shard_pack_blocks(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t per_rank, uint32_t nchunks,
+                          uint32_t nranks, const uint32_t *d_nsub, const int32_t *d_status, const uint32_t *d_ev_idx,
+                          const double *d_ev_time, const double *d_nf_last_t, const double *d_final_state, const float *d_lbs,
+                          const float *d_ubs, const float *d_recs, void *d_records)
+{
+    if (first > n || count > n - first || count > per_rank) {
+        return ctx->invalid("csc_shard_pack_blocks: the range does not lie within the particles (or exceeds per_rank)");
+    }
+    if (nranks == 0u || nranks > 65535u || nchunks == 0u) {
+        return ctx->invalid("csc_shard_pack_blocks: needs 1 <= nranks <= 65535 and at least one chunk");
+    }
+    if (count == 0u) {
+        return CSC_OK;
+    }
+    shard_arrays a{const_cast<uint32_t *>(d_nsub), const_cast<int32_t *>(d_status), const_cast<uint32_t *>(d_ev_idx),
+                   const_cast<double *>(d_ev_time), const_cast<double *>(d_nf_last_t), const_cast<double *>(d_final_state),
+                   reinterpret_cast<float4 *>(const_cast<float *>(d_lbs)), reinterpret_cast<float4 *>(const_cast<float *>(d_ubs)),
+                   reinterpret_cast<float4 *>(const_cast<float *>(d_recs))};
+    KT("k_shard_pack", hipLaunchKernelGGL((k_shard_records<false>), dim3(cdiv(count, 256), nranks), dim3(256), 0, ctx->stream, first,
+                                           count, n, per_rank, nchunks, cdiv(nchunks, nranks), 0u, 0u, a,
+                                           static_cast<unsigned char *>(d_records)));
+    CSC_LAUNCH_CHECK();
+    return CSC_OK;
+}
+
+int csc_shard_unpack_block(csc_ctx *ctx, uint32_t n, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_count,
+                           const void *d_records, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
+                           double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs)
+{
+    if (chunk_first > nchunks || chunk_count > nchunks - chunk_first) {
+        return ctx->invalid("csc_shard_unpack_block: the block does not lie within the chunks");
+    }
+    if (n == 0u) {
+        return CSC_OK;
+    }
+    shard_arrays a{d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, reinterpret_cast<float4 *>(d_lbs),
+                   reinterpret_cast<float4 *>(d_ubs), reinterpret_cast<float4 *>(d_recs)};
+    KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, 0u, n, n, n, nchunks,
+                                             nchunks, chunk_first, chunk_first + chunk_count, a,
+                                             static_cast<unsigned char *>(const_cast<void *>(d_records))));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -1206,8 +1279,8 @@ int csc_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const void *d_r
     }
     shard_arrays a{d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, reinterpret_cast<float4 *>(d_lbs),
                    reinterpret_cast<float4 *>(d_ubs), reinterpret_cast<float4 *>(d_recs)};
-    KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, 0u, n, n, nchunks, a,
-                                             static_cast<unsigned char *>(const_cast<void *>(d_records))));
+    KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, 0u, n, n, n, nchunks,
+                                             nchunks, 0u, nchunks, a, static_cast<unsigned char *>(const_cast<void *>(d_records))));
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }

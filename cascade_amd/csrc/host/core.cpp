@@ -333,8 +333,9 @@ PYBIND11_MODULE(core, m)
             "rank"_a, "nranks"_a, "exchange"_a = py::none{})
         .def(
             "set_shard_propagation",
-            [](sim &s, py::object gather, bool chunks) {
-                // gather(send_address, recv_address, nbytes): all-gather of device memory.
+            [](sim &s, py::object gather, bool chunks, py::object alltoall) {
+                // gather(send_address, recv_address, nbytes): all-gather of device memory;
+                // alltoall(send_address, recv_address, send_bytes list, recv_bytes_each).
                 sim::gather_t fn;
                 if (!gather.is_none()) {
                     fn = [gather](std::uintptr_t send, std::uintptr_t recv, std::size_t bytes) {
@@ -342,9 +343,17 @@ PYBIND11_MODULE(core, m)
                         gather(send, recv, bytes);
                     };
                 }
-                s.set_shard_propagation(std::move(fn), chunks);
+                sim::alltoall_t fa;
+                if (!alltoall.is_none()) {
+                    fa = [alltoall](std::uintptr_t send, std::uintptr_t recv, const std::vector<std::size_t> &seg, std::size_t each) {
+                        py::gil_scoped_acquire gil;
+                        alltoall(send, recv, seg, each);
+                    };
+                }
+                s.set_shard_propagation(std::move(fn), chunks, std::move(fa));
             },
-            "gather"_a = py::none{}, "chunks"_a = true)
+            "gather"_a = py::none{}, "chunks"_a = true, "alltoall"_a = py::none{})
+        .def_property_readonly("last_exchanged_bytes", [](const sim &s) { return s.get_step_stats().exchanged_bytes; })
         .def_property_readonly("last_chunk_block", [](const sim &s) { return std::make_pair(s.get_step_stats().chunk_first, s.get_step_stats().chunk_count); })
         .def_property_readonly("_conj_segments",
                                [](const sim &s) {

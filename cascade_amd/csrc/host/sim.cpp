@@ -438,6 +438,7 @@ struct sim::sim_data {
     exchange_t exchange;
     gather_t gather; // propagation sharded too when set
     bool shard_chunks = true;                 // ... and, with n_par_ct >= nranks, the chunks dealt to the processes
+    alltoall_t alltoall;                      // ... receiving the records of the own chunks only
     std::uint32_t chunk_c0 = 0, chunk_cl = 0; // chunk block of the last step on this process
     // Hashes of the host state / parameter vectors as of the last transfer (csc_upload /
     // csc_download): when they still match at the next step(), the caller has not edited the
@@ -465,7 +466,7 @@ struct sim::sim_data {
         : dyn(o.dyn), tape(o.tape), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
           single_pass_mode(o.single_pass_mode),
-          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather), shard_chunks(o.shard_chunks)
+          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather), shard_chunks(o.shard_chunks), alltoall(o.alltoall)
     {
     }
     ~sim_data()
@@ -966,10 +967,11 @@ void sim::set_shard(std::uint32_t rank, std::uint32_t nranks, exchange_t exchang
     m_data->exchange = std::move(exchange);
 }
 
-void sim::set_shard_propagation(gather_t gather, bool chunks)
+void sim::set_shard_propagation(gather_t gather, bool chunks, alltoall_t alltoall)
 {
     m_data->gather = std::move(gather);
     m_data->shard_chunks = chunks;
+    m_data->alltoall = std::move(alltoall);
 }
 
 void sim::set_np_prefilter(bool v)
@@ -1310,6 +1312,8 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     // Propagation sharded over the processes: pass 1 without rows on this process's range, then
     // one all-gather; the rows are produced on demand whatever the dynamics.
     const bool shard_prop = d.shard_n > 1u && static_cast<bool>(d.gather) && d.np_prefilter;
+    // ... and the chunks dealt to the processes when there is at least one for each.
+    const bool chunk_mode = shard_prop && d.shard_chunks && nchunks0 >= d.shard_n;
     const bool sparse = shard_prop
                         || (d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && !from_tape && d.sparse_likely
                             && !d.want_full_rows);
@@ -1332,24 +1336,53 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     } else if (shard_prop) {
         const std::uint32_t per = (n + d.shard_n - 1u) / d.shard_n;
         const std::uint32_t first = std::min(n, d.shard_rank * per), count = std::min(per, n - first);
-        const std::size_t rec = csc_shard_record_bytes(nchunks0);
-        auto *d_send = d.buf<unsigned char>("shard_send", static_cast<std::size_t>(per) * rec);
-        auto *d_recv = d.buf<unsigned char>("shard_recv", static_cast<std::size_t>(per) * d.shard_n * rec);
         d.chk(csc_propagate_range(ctx, &cfg, n, first, count, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final,
                                   d_lbs, d_ubs, d_recs));
-        d.chk(csc_shard_pack(ctx, n, first, count, nchunks0, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
-                             d_recs, d_send));
-        d.chk(csc_sync(ctx));
-        d.gather(reinterpret_cast<std::uintptr_t>(d_send), reinterpret_cast<std::uintptr_t>(d_recv),
-                 static_cast<std::size_t>(per) * rec);
+        if (chunk_mode && d.alltoall) {
+            // Every process needs the per-chunk records of its own block of chunks only.
+            std::vector<std::size_t> seg(d.shard_n);
+            std::size_t total = 0;
+            std::uint32_t my_c0 = 0, my_cl = 0;
+            for (std::uint32_t r = 0; r < d.shard_n; ++r) {
+                std::uint32_t bf = 0, bc = 0;
+                d.chk(csc_shard_block(nchunks0, d.shard_n, r, &bf, &bc));
+                seg[r] = static_cast<std::size_t>(per) * csc_shard_record_bytes(bc);
+                total += seg[r];
+                if (r == d.shard_rank) {
+                    my_c0 = bf;
+                    my_cl = bc;
+                }
+            }
+            const std::size_t each = static_cast<std::size_t>(per) * csc_shard_record_bytes(my_cl);
+            auto *d_send = d.buf<unsigned char>("shard_send", total);
+            auto *d_recv = d.buf<unsigned char>("shard_recv", each * d.shard_n);
+            d.chk(csc_shard_pack_blocks(ctx, n, first, count, per, nchunks0, d.shard_n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t,
+                                        d_final, d_lbs, d_ubs, d_recs, d_send));
+            d.chk(csc_sync(ctx));
+            d.alltoall(reinterpret_cast<std::uintptr_t>(d_send), reinterpret_cast<std::uintptr_t>(d_recv), seg, each);
+            d.chk(csc_shard_unpack_block(ctx, n, nchunks0, my_c0, my_cl, d_recv, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t,
+                                         d_final, d_lbs, d_ubs, d_recs));
+            d.stats.exchanged_bytes = each * d.shard_n;
+        } else {
+            const std::size_t rec = csc_shard_record_bytes(nchunks0);
+            auto *d_send = d.buf<unsigned char>("shard_send", static_cast<std::size_t>(per) * rec);
+            auto *d_recv = d.buf<unsigned char>("shard_recv", static_cast<std::size_t>(per) * d.shard_n * rec);
+            d.chk(csc_shard_pack(ctx, n, first, count, nchunks0, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs,
+                                 d_ubs, d_recs, d_send));
+            d.chk(csc_sync(ctx));
+            d.gather(reinterpret_cast<std::uintptr_t>(d_send), reinterpret_cast<std::uintptr_t>(d_recv),
+                     static_cast<std::size_t>(per) * rec);
+            d.chk(csc_shard_unpack(ctx, n, nchunks0, d_recv, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
+                                   d_recs));
+            d.stats.exchanged_bytes = static_cast<std::size_t>(per) * d.shard_n * rec;
+        }
         d.stats.propagated = count;
-        d.chk(csc_shard_unpack(ctx, n, nchunks0, d_recv, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
-                               d_recs));
     } else {
         d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
     }
     if (!shard_prop) {
         d.stats.propagated = n;
+        d.stats.exchanged_bytes = 0;
     }
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
@@ -1400,9 +1433,9 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     // the tree of, traverses and narrow-phases ITS block of chunks [c0, c0 + cl) only -- nothing
     // but the integration's all-gather is shared, nothing is replicated. (Otherwise: all chunks
     // here, the pair tree of every chunk sharded over the processes.)
-    const bool chunk_mode = shard_prop && d.shard_chunks && nchunks0 >= d.shard_n;
     std::uint32_t c0 = 0, cl = nchunks;
     if (chunk_mode) {
+        // (csc_shard_block's rule on nchunks0, cut to the chunks a stopping event left)
         const std::uint32_t per_c = (nchunks0 + d.shard_n - 1u) / d.shard_n;
         c0 = std::min(nchunks, d.shard_rank * per_c);
         cl = std::min(per_c, nchunks - c0);

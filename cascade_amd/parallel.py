@@ -10,7 +10,8 @@ Every process holds the same simulation (same state, same calls). Per superstep
      simulation's device buffers (``make_device_gather``);
   3. with ``n_par_ct >= world`` every process owns a block of the superstep's chunks -- chunks
      are independent once the trajectories are known -- and sorts, builds the trees of, traverses
-     and narrow-phases only those: nothing is replicated. With fewer chunks than processes every
+     and narrow-phases only those: nothing is replicated, and step 2 becomes ONE all-to-all that
+     brings a process the per-chunk records of its own chunks only (``make_device_alltoall``). With fewer chunks than processes every
      process sorts and builds the whole tree of every chunk (replicated: cheaper than a distributed
      sort at these sizes, and bit-identical everywhere), expands only its share of each pair tree
      and runs the narrow phase on the pairs it found. Either way Taylor rows are produced on demand
@@ -76,19 +77,52 @@ def make_device_gather(group=None):
     return gather
 
 
-def shard(sim_obj, group=None, propagation=True, chunks=True):
+def make_device_alltoall(group=None):
+    """alltoall(send_address, recv_address, send_bytes, recv_bytes_each): process r receives
+    ``send_bytes[r]`` consecutive bytes of every process's send buffer (``recv_bytes_each`` from
+    each, rank-major). RCCL moves device memory in place; gloo (the CPU tests) stages through
+    host memory."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    on_device = dist.get_backend(group) == "nccl"
+
+    def alltoall(send_address, recv_address, send_bytes, recv_bytes_each):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        send_bytes = [int(b) for b in send_bytes]
+        assert len(send_bytes) == world
+        send = torch.as_tensor(_DeviceBytes(send_address, sum(send_bytes)), device=dev)
+        recv = torch.as_tensor(_DeviceBytes(recv_address, recv_bytes_each * world), device=dev)
+        if on_device:
+            dist.all_to_all_single(recv, send, [recv_bytes_each] * world, send_bytes, group=group)
+        else:
+            out = torch.empty(recv_bytes_each * world, dtype=torch.uint8)
+            dist.all_to_all_single(out, send.cpu(), [recv_bytes_each] * world, send_bytes, group=group)
+            recv.copy_(out)
+        torch.cuda.synchronize(dev)
+
+    return alltoall
+
+
+def shard(sim_obj, group=None, propagation=True, chunks=True, alltoall=True):
     """Shard ``sim_obj`` over the processes of ``group`` (call it on every process, on
     simulations constructed from the same arguments). ``propagation=False`` keeps the integration
     replicated on every process (no all-gather of the per-particle records). ``chunks`` (with
     the propagation sharded and ``n_par_ct >= world``): every process also owns a block of the
     superstep's chunks and sorts / builds / traverses / narrow-phases only those -- nothing is
-    replicated; ``chunks=False`` keeps every chunk on every process with its pair tree sharded."""
+    replicated; ``chunks=False`` keeps every chunk on every process with its pair tree sharded.
+    ``alltoall`` (with the chunks dealt out): the exchange of step 2 is an all-to-all in which a
+    process receives the per-chunk records of ITS chunks only (80 + 96 * own chunks bytes per
+    particle instead of 80 + 96 C); ``alltoall=False`` keeps the all-gather."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if world > 1:
         sim_obj.set_shard(rank, world, make_summary_exchange(group))
-        sim_obj.set_shard_propagation(make_device_gather(group) if propagation else None, chunks)
+        sim_obj.set_shard_propagation(
+            make_device_gather(group) if propagation else None, chunks, make_device_alltoall(group) if propagation and chunks and alltoall else None
+        )
     return sim_obj
 
 

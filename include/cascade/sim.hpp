@@ -213,6 +213,7 @@ public:
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles
         std::uint32_t nchunks = 0;        // chunks actually processed (after an event shrink)
         std::uint32_t chunk_first = 0, chunk_count = 0; // the block of them this process handled (all, unless the chunks are sharded)
+        std::uint64_t exchanged_bytes = 0;              // received by this process in the per-particle exchange (0: not sharded)
         std::uint64_t stored_objects = 0; // particles whose Taylor rows were written (all, or those of the candidate pairs)
         std::uint32_t np_attempts = 0;    // narrow-phase passes (more than one per call: an output list overflowed and was grown)
     };
@@ -411,7 +412,13 @@ public:
     // chunks (default on): with n_par_ct >= nranks each process then also owns a block of the
     // n_par_ct chunks -- it sorts, builds, traverses and narrow-phases those chunks only (chunks are
     // independent once the trajectories are known), so nothing of the superstep is replicated.
-    void set_shard_propagation(gather_t gather, bool chunks = true);
+    // alltoall (optional; used when the chunks are dealt out): alltoall(send, recv, send_bytes,
+    // recv_bytes_each) sends send_bytes[r] consecutive bytes from the device address `send` to
+    // process r and receives recv_bytes_each bytes from every process into `recv` (rank-major).
+    // A process then receives the boxes and trajectory records of ITS chunks only: 80 + 96 *
+    // (chunks of its block) bytes per particle instead of 80 + 96 C.
+    using alltoall_t = std::function<void(std::uintptr_t, std::uintptr_t, const std::vector<std::size_t> &, std::size_t)>;
+    void set_shard_propagation(gather_t gather, bool chunks = true, alltoall_t alltoall = {});
     // Geometric pre-filter in front of the polynomial narrow phase (on by default; it never
     // changes the detected events, see k_np_prefilter).
     void set_np_prefilter(bool);

@@ -402,6 +402,25 @@ int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uin
 int csc_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const void *d_records, uint32_t *d_nsub, int32_t *d_status,
                      uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t, double *d_final_state, float *d_lbs,
                      float *d_ubs, float *d_recs);
+/* The same exchange when the chunks are dealt to the processes as well (csc_set_chunk_map): the
+ * process that owns a block of chunks needs the boxes and trajectory records of THOSE chunks
+ * only, so an all-to-all replaces the all-gather and moves 80 + 96 * (chunks of the block) bytes
+ * per particle instead of 80 + 96 C. csc_shard_block: the block of `rank` -- blocks of
+ * ceil(nchunks / nranks) consecutive chunks in rank order until the chunks run out (count may
+ * be 0). csc_shard_pack_blocks writes nranks segments into d_records, segment r =
+ * per_rank records of csc_shard_record_bytes(count_r) bytes holding the chunks of block r
+ * (particle first + k -> record k of every segment; segment r starts at
+ * per_rank * (80 r + 96 first_r) bytes); after an all-to-all in which every process sends
+ * segment r to process r, csc_shard_unpack_block scatters the nranks equal segments received
+ * (record i = particle i, chunks [chunk_first, chunk_first + chunk_count)). Asynchronous. */
+int csc_shard_block(uint32_t nchunks, uint32_t nranks, uint32_t rank, uint32_t *first, uint32_t *count);
+int csc_shard_pack_blocks(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t per_rank, uint32_t nchunks,
+                          uint32_t nranks, const uint32_t *d_nsub, const int32_t *d_status, const uint32_t *d_ev_idx,
+                          const double *d_ev_time, const double *d_nf_last_t, const double *d_final_state, const float *d_lbs,
+                          const float *d_ubs, const float *d_recs, void *d_records);
+int csc_shard_unpack_block(csc_ctx *ctx, uint32_t n, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_count,
+                           const void *d_records, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
+                           double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs);
 
 /* ---- K8: dense output ------------------------------------------------------------------
  * dense_propagate (src/sim_propagate.cpp:1386-1503): state of every particle at time t

@@ -122,13 +122,14 @@ def main():
             c = np.concatenate(objs)
             return c[np.lexsort((c["j"], c["i"], c["time"]))]
 
-        # (a) chunks dealt to the processes (n_par_ct = 3 and 7: even and ragged blocks), (b) every
-        # chunk everywhere with its pair tree sharded.
-        for n_par_ct, chunks in [(3, True), (7, True), (3, False)]:
+        # (a) chunks dealt to the processes (n_par_ct = 3 and 7: even and ragged blocks), the
+        # per-particle records by all-to-all (own chunks only) or by all-gather, (b) every chunk
+        # everywhere with its pair tree sharded.
+        for n_par_ct, chunks, a2a in [(3, True, True), (7, True, True), (7, True, False), (3, False, False)]:
             st = random_leo_pop_kep(6001, seed=21)
             st[:, 6] *= 3e4
             full = sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=1e-3, device=dev)
-            part = shard(sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=1e-3, device=dev), propagation=True, chunks=chunks)
+            part = shard(sim(st.copy(), 0.23, n_par_ct=n_par_ct, conj_thresh=1e-3, device=dev), propagation=True, chunks=chunks, alltoall=a2a)
             events = 0
             for _ in range(4):
                 of, op = full.step(), part.step()
@@ -147,6 +148,12 @@ def main():
                     assert (c0, cl) == (min(n_par_ct, rank * per_c), max(0, min(per_c, n_par_ct - rank * per_c))), (rank, c0, cl)
                 elif not chunks:
                     assert c0 == 0 and cl == full.last_nchunks
+                if a2a:
+                    per_c = -(-n_par_ct // world)
+                    mine = max(0, min(per_c, n_par_ct - rank * per_c))
+                    assert part.last_exchanged_bytes == world * per * (80 + 96 * mine), (rank, part.last_exchanged_bytes)
+                else:
+                    assert part.last_exchanged_bytes == world * per * (80 + 96 * n_par_ct)
                 events += len(full.last_collisions) + len(full.last_step_conjunctions)
             of, op = full.propagate_until(full.time + 1.0), part.propagate_until(part.time + 1.0)
             assert of == op and full.time == part.time and np.array_equal(full.state, part.state)
