@@ -93,7 +93,8 @@ struct csc_ctx {
     const unsigned long long *bp_flat_pairs = nullptr;
     uint32_t bp_flat_cap = 0;
     uint32_t bp_flat_cnt[csc::DT_SHARDS] = {};
-    uint32_t dt_fr_cap = 0, dt_pair_cap = 0;
+    uint32_t dt_fr_cap = 0, dt_pair_cap = 0, dt_tile_cap = 0;
+    uint64_t bp_tiles = 0; // tiles of the last dual traversal
     uint64_t bp_node_pairs = 0;
     int bp_mode = -1; // -1: read CASCADE_BP_MODE once; 0 per-particle walks, 1 dual traversal
     unsigned long long *d_bp_counter = nullptr;
@@ -1666,17 +1667,20 @@ int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
 static_assert(csc::NP_FLAT_SHARDS == csc::DT_SHARDS, "flat pair lists");
 static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                             const uint32_t *d_vidx, const uint8_t *d_active, const csc::tnode *d_tn, const uint8_t *d_sact,
-                            uint64_t *n_pairs)
+                            const uint32_t *d_sinfo, const uint32_t *d_sleaf, uint32_t tile_max, uint64_t *n_pairs)
 {
     using namespace csc;
     const size_t ctr_per_level = static_cast<size_t>(DT_SHARDS) * DT_CTR_STRIDE;
-    CSC_BUF(d_cnt, uint32_t, "dt_counters", ctr_per_level * (DT_MAX_LEVELS + 2));
+    CSC_BUF(d_cnt, uint32_t, "dt_counters", ctr_per_level * (DT_MAX_LEVELS + 3));
     uint32_t *d_pair_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 1);
+    uint32_t *d_tile_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 2);
+    // Tiles: about 6 per particle at 1M objects with tiles of 16.
+    uint32_t tile_cap = tile_max ? std::max<uint32_t>({ctx->dt_tile_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u}) : 1u;
     // First guesses: 4 frontier items and 8 pairs per particle and chunk; afterwards what the last
     // superstep needed (populations change slowly), and an overflow redoes the traversal.
     uint32_t fr_cap = std::max<uint32_t>({ctx->dt_fr_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 4u, 4096u});
     uint32_t pair_cap = std::max<uint32_t>({ctx->dt_pair_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u});
-    std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 2));
+    std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 3));
     // Workgroups per shard (each strides over the DT_BLOCK-item tiles of its shard): 512 of 128
     // threads, i.e. 16384 workgroups in all, measured best at 1M objects (per traversal: 1.65 ms
     // with 64 x 256 threads, 1.47 with 256 x 256, 1.42 with 512 x 128, 1.45 with 1024 x 128, 1.47
@@ -1691,6 +1695,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         CSC_BUF(d_fa, unsigned long long, "dt_frontier_a", static_cast<size_t>(fr_cap) * DT_SHARDS);
         CSC_BUF(d_fb, unsigned long long, "dt_frontier_b", static_cast<size_t>(fr_cap) * DT_SHARDS);
         CSC_BUF(d_pairs, unsigned long long, "dt_pairs", static_cast<size_t>(pair_cap) * DT_SHARDS);
+        CSC_BUF(d_tiles, unsigned long long, "dt_tiles", static_cast<size_t>(tile_cap) * DT_SHARDS);
         CSC_HIP(hipMemsetAsync(d_cnt, 0, hc.size() * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_bp_dual_init, dim3(cdiv(nchunks, 64)), dim3(64), 0, ctx->stream, nchunks, ctx->bvh.nn_max, ctx->bvh.nleft,
                            d_fa, d_cnt);
@@ -1714,6 +1719,12 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         q.shard_level = 12;
         q.shard_rank = ctx->shard_rank;
         q.shard_n = ctx->shard_n;
+        q.tile_max = tile_max;
+        q.tiles = d_tiles;
+        q.tile_cnt = d_tile_cnt;
+        q.tile_cap = tile_cap;
+        q.sinfo = d_sinfo;
+        q.sleaf = d_sleaf;
         int level = 0;
         bool done = false;
         ctx->kt_begin("k_bp_dual");
@@ -1752,11 +1763,29 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
             ctx->err = "broad phase: the dual traversal did not terminate";
             return CSC_ERR_OVERFLOW;
         }
+        if (tile_max != 0u) {
+            // Workgroups stride over the tile batches of their shard: 8 per CU fill the chip.
+            const unsigned tg = DT_SHARDS * (static_cast<uint64_t>(n) * nchunks >= 200000u ? 64u : 8u);
+            if (tile_max <= 8u) {
+                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            } else {
+                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<16>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            }
+            CSC_LAUNCH_CHECK();
+        }
         CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, ctr_per_level * (level + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, ctr_per_level * sizeof(uint32_t),
+        CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 2 * ctr_per_level * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
-        uint32_t max_fr = 0, max_pr = 0;
+        uint32_t max_fr = 0, max_pr = 0, max_tl = 0;
+        uint64_t ntiles = 0;
+        for (int s = 0; s < DT_SHARDS; ++s) {
+            const uint32_t v = hc[ctr_per_level * (DT_MAX_LEVELS + 2) + static_cast<size_t>(s) * DT_CTR_STRIDE];
+            max_tl = std::max(max_tl, v);
+            ntiles += v;
+        }
+        ctx->bp_tiles = ntiles;
+        ctx->dt_tile_cap = std::max(ctx->dt_tile_cap, max_tl + max_tl / 4u + 1024u);
         uint64_t items = 0;
         int used_levels = 0;
         ctx->dt_level_items.assign(static_cast<size_t>(level) + 1u, 0);
@@ -1784,7 +1813,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         }
         ctx->dt_fr_cap = std::max(ctx->dt_fr_cap, max_fr + max_fr / 4u + 1024u);
         ctx->dt_pair_cap = std::max(ctx->dt_pair_cap, max_pr + max_pr / 4u + 1024u);
-        if (max_fr <= fr_cap && max_pr <= pair_cap) {
+        if (max_fr <= fr_cap && max_pr <= pair_cap && max_tl <= tile_cap) {
             ctx->bp_flat = true;
             ctx->bp_flat_pairs = d_pairs;
             ctx->bp_flat_cap = pair_cap;
@@ -1797,9 +1826,13 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         }
         // A frontier or the pair list overflowed (the counters kept counting): grow and redo. A
         // truncated frontier hides part of what follows, hence the generous factor.
-        const bool truncated = max_fr > fr_cap;
-        if (truncated) {
+        const bool fr_over = max_fr > fr_cap;
+        const bool truncated = fr_over || max_tl > tile_cap;
+        if (fr_over) {
             fr_cap = max_fr * 4u;
+        }
+        if (fr_over || max_tl > tile_cap) {
+            tile_cap = std::max(tile_cap, max_tl * (fr_over ? 4u : 1u) + max_tl / 4u + 1024u);
         }
         if (truncated || max_pr > pair_cap) {
             pair_cap = std::max(pair_cap, max_pr * (truncated ? 4u : 1u) + max_pr / 4u + 1024u);
@@ -1820,18 +1853,35 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     // Wide traversal nodes (need the Morton permutation and the activity flags for the leaf
     // descriptors, so they are rebuilt on every call).
     CSC_BUF(d_sact, uint8_t, "bvh_sorted_active", static_cast<size_t>(ctx->bvh_chunks) * n);
-    KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
-                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn, d_sact));
-    CSC_LAUNCH_CHECK();
-    ctx->bvh_packed = true;
     if (ctx->bp_mode < 0) {
         const char *e = std::getenv("CASCADE_BP_MODE");
         ctx->bp_mode = (e && std::string(e) == "walk") ? 0 : 1;
     }
+    // Tiles at the bottom of the dual traversal (k_bp_tiles): ranges of up to 8 particles
+    // (measured best at 1M objects: traversal + tiles 0.57 + 0.55 ms per chunk, against 0.41 + 0.93
+    // with 16 and 1.56 + 0 without tiles), positions below 2^24. CASCADE_DT_TILE overrides (0:
+    // none, at most 16; measurements).
+    const bool dual = ctx->bp_mode == 1 && ctx->bvh.nn_max < csc::DT_MAX_NODES && nchunks <= csc::DT_MAX_CHUNKS;
+    uint32_t tile_max = 0;
+    if (dual && n < csc::DT_TILE_MAX_N) {
+        const char *e = std::getenv("CASCADE_DT_TILE");
+        tile_max = e ? std::min<uint32_t>(static_cast<uint32_t>(std::max(0, std::atoi(e))), csc::DT_TILE_LIMIT) : 8u;
+    }
+    uint32_t *d_sinfo = nullptr, *d_sleaf = nullptr;
+    if (tile_max != 0u) {
+        CSC_BUF(d_si, uint32_t, "bvh_sorted_info", static_cast<size_t>(ctx->bvh_chunks) * n);
+        CSC_BUF(d_sl, uint32_t, "bvh_sorted_leaf", static_cast<size_t>(ctx->bvh_chunks) * n);
+        d_sinfo = d_si;
+        d_sleaf = d_sl;
+    }
+    KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
+                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf));
+    CSC_LAUNCH_CHECK();
+    ctx->bvh_packed = true;
     ctx->bp_flat = false;
     ctx->bp_node_pairs = 0;
-    if (ctx->bp_mode == 1 && ctx->bvh.nn_max < csc::DT_MAX_NODES && nchunks <= csc::DT_MAX_CHUNKS) {
-        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, n_pairs);
+    if (dual) {
+        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, tile_max, n_pairs);
     }
     csc::bp_params q{};
     q.n = n;
@@ -1983,8 +2033,10 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
                     continue;
                 }
                 if (k < cap) {
-                    pairs[k * 2u] = vx[static_cast<uint32_t>(rec) & 0xfffffffu];
-                    pairs[k * 2u + 1u] = vx[static_cast<uint32_t>(rec >> 28) & 0xfffffffu];
+                    // (the tile kernel records positions in no particular order)
+                    const uint32_t oa = vx[static_cast<uint32_t>(rec) & 0xfffffffu], ob = vx[static_cast<uint32_t>(rec >> 28) & 0xfffffffu];
+                    pairs[k * 2u] = std::min(oa, ob);
+                    pairs[k * 2u + 1u] = std::max(oa, ob);
                 }
                 ++k;
             }

@@ -23,8 +23,8 @@
 // regions, each with its own counter on its own cache line: same-address atomics from
 // thousands of workgroups serialise at ~13 ns each.
 //
-// A pair is recorded as pos_a | pos_b << 28 | chunk << 56 (sorted positions within the chunk,
-// orig(pos_a) < orig(pos_b)). Limits of this encoding: 2^26 nodes per chunk, 256 chunks; the
+// A pair is recorded as pos_a | pos_b << 28 | chunk << 56 (sorted positions within the chunk; the
+// readers of the list order the two by original index). Limits of this encoding: 2^26 nodes per chunk, 256 chunks; the
 // caller falls back on k_broad_phase beyond them.
 //
 // Multi-GPU: every process expands the first levels completely (a few thousand items), at
@@ -63,6 +63,14 @@ struct dual_params {
     std::uint32_t *pair_cnt;      // [DT_SHARDS * DT_CTR_STRIDE]
     std::uint32_t pair_cap;
     std::uint32_t level, shard_level, shard_rank, shard_n;
+    // Tiles (see k_bp_tiles): a child pair whose two particle ranges hold at most tile_max
+    // particles each is not descended into but recorded; 0 = no tiles.
+    std::uint32_t tile_max;
+    unsigned long long *tiles;    // [DT_SHARDS][tile_cap]
+    std::uint32_t *tile_cnt;      // [DT_SHARDS * DT_CTR_STRIDE]
+    std::uint32_t tile_cap;
+    const std::uint32_t *sinfo;   // [C][n] orig | act << 24 | multi-leaf member << 26 (k_bvh_pack)
+    const std::uint32_t *sleaf;   // [C][n] leaf of a multi-leaf member
 };
 
 enum : std::uint32_t { DT_INTERNAL = 0, DT_LEAF1 = 1, DT_LEAFN = 2 };
@@ -76,6 +84,16 @@ CSC_DEV unsigned long long dt_item(std::uint32_t a, std::uint32_t ak, std::uint3
 CSC_DEV unsigned long long dt_pair(std::uint32_t pa, std::uint32_t pb, std::uint32_t c)
 {
     return static_cast<unsigned long long>(pa) | (static_cast<unsigned long long>(pb) << 28)
+           | (static_cast<unsigned long long>(c) << 56);
+}
+// A tile: the particle ranges [xb, xb + xn) x [yb, yb + yn) of one chunk, 1 <= xn, yn <= 16,
+// positions below 2^24; xb == yb: a range against itself.
+constexpr std::uint32_t DT_TILE_LIMIT = 16;
+constexpr std::uint32_t DT_TILE_MAX_N = 1u << 24;
+CSC_DEV unsigned long long dt_tile(std::uint32_t xb, std::uint32_t xn, std::uint32_t yb, std::uint32_t yn, std::uint32_t c)
+{
+    return static_cast<unsigned long long>(xb) | (static_cast<unsigned long long>(yb) << 24)
+           | (static_cast<unsigned long long>(xn - 1u) << 48) | (static_cast<unsigned long long>(yn - 1u) << 52)
            | (static_cast<unsigned long long>(c) << 56);
 }
 CSC_DEV std::uint32_t dt_hash(unsigned long long v)
@@ -155,6 +173,7 @@ __global__ void k_bp_dual_init(std::uint32_t nchunks, std::uint32_t nn_max, cons
 struct dt_kid {
     float4 lb, ub;
     std::uint32_t val, kind, orig, act;
+    std::uint32_t beg, cnt; // particle range
 };
 
 CSC_DEV dt_kid dt_kid_from_desc(const float4 &lb, const float4 &ub, const int4 &c)
@@ -169,6 +188,8 @@ CSC_DEV dt_kid dt_kid_from_desc(const float4 &lb, const float4 &ub, const int4 &
     s.val = !leaf ? static_cast<std::uint32_t>(c.x) : (end - begin == 1u ? begin : (code >> 2));
     s.act = code & 3u;
     s.orig = static_cast<std::uint32_t>(c.w);
+    s.beg = begin;
+    s.cnt = end - begin;
     return s;
 }
 
@@ -200,7 +221,12 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
         unsigned long long *pout = q.pairs + static_cast<std::size_t>(oshard) * q.pair_cap;
         std::uint32_t *out_cnt = q.out_cnt + oshard * DT_CTR_STRIDE;
         std::uint32_t *pair_cnt = q.pair_cnt + oshard * DT_CTR_STRIDE;
-        // One output per (statically numbered) child pair: kind 1 = frontier item, 2 = pair.
+        // Second output channel: the pair list, or the tile list when tiles are on (then the only
+        // pairs this kernel writes itself are those of oversized multi-particle leaves).
+        unsigned long long *out2 = q.tile_max ? q.tiles + static_cast<std::size_t>(oshard) * q.tile_cap : pout;
+        std::uint32_t *out2_cnt = q.tile_max ? q.tile_cnt + oshard * DT_CTR_STRIDE : pair_cnt;
+        const std::uint32_t out2_cap = q.tile_max ? q.tile_cap : q.pair_cap;
+        // One output per (statically numbered) child pair: kind 1 = frontier item, 2 = pair / tile.
         unsigned long long rec_out[4] = {0, 0, 0, 0};
         std::uint32_t kind[4] = {0, 0, 0, 0};
         if (k < cnt) {
@@ -269,10 +295,14 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
                         x0.ub = q.sub[po + v];
                         x0.orig = q.vidx[po + v];
                         x0.act = q.sact[po + v];
+                        x0.beg = v;
+                        x0.cnt = 1u;
                     } else {
                         x0.lb = q.nlb[no + v];
                         x0.ub = q.nub[no + v];
-                        x0.orig = q.vidx[po + q.nb[no + v]];
+                        x0.beg = q.nb[no + v];
+                        x0.cnt = q.ne[no + v] - x0.beg;
+                        x0.orig = q.vidx[po + x0.beg];
                         x0.act = q.active[x0.orig];
                     }
                     x1 = x0;
@@ -287,11 +317,26 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
                 if (self_kid) {
                     // (a single-particle leaf has no pair with itself)
                     if (x.kind != DT_LEAF1) {
-                        const unsigned long long rec = dt_item(x.val, x.kind, x.val, x.kind, c);
-                        if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
-                            rec_out[slot] = rec;
-                            kind[slot] = 1u;
+                        if (x.cnt <= q.tile_max) {
+                            const unsigned long long rec = dt_tile(x.beg, x.cnt, x.beg, x.cnt, c);
+                            if (!deal_pairs || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                                rec_out[slot] = rec;
+                                kind[slot] = 2u;
+                            }
+                        } else {
+                            const unsigned long long rec = dt_item(x.val, x.kind, x.val, x.kind, c);
+                            if (!deal_items || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                                rec_out[slot] = rec;
+                                kind[slot] = 1u;
+                            }
                         }
+                    }
+                } else if (x.cnt <= q.tile_max && y.cnt <= q.tile_max) {
+                    // (tile_max != 0 here; covers leaf x leaf as a 1 x 1 tile)
+                    const unsigned long long rec = dt_tile(x.beg, x.cnt, y.beg, y.cnt, c);
+                    if (!deal_pairs || dt_hash(rec) % q.shard_n == q.shard_rank) {
+                        rec_out[slot] = rec;
+                        kind[slot] = 2u;
                     }
                 } else if (x.kind == DT_LEAF1 && y.kind == DT_LEAF1) {
                     if ((x.act | y.act) != 0u) {
@@ -374,7 +419,7 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
         }
         if (threadIdx.x == 0) {
             s_base[0] = tot_f ? atomicAdd(out_cnt, tot_f) : 0u;
-            s_base[1] = tot_p ? atomicAdd(pair_cnt, tot_p) : 0u;
+            s_base[1] = tot_p ? atomicAdd(out2_cnt, tot_p) : 0u;
         }
         __syncthreads();
         std::uint32_t pos_f = s_base[0] + off_f, pos_p = s_base[1] + off_p;
@@ -386,13 +431,244 @@ __global__ __launch_bounds__(DT_BLOCK) void k_bp_dual(const dual_params q)
                 }
                 ++pos_f;
             } else if (kind[j] == 2u) {
-                if (pos_p < q.pair_cap) {
-                    pout[pos_p] = rec_out[j];
+                if (pos_p < out2_cap) {
+                    out2[pos_p] = rec_out[j];
                 }
                 ++pos_p;
             }
         }
         __syncthreads();
+    }
+}
+
+// The tiles of the traversal above: every particle pair of a tile gets the reference's own leaf
+// test directly -- the particle with the smaller original index queries the box of the other
+// one's LEAF (src/sim_broad_phase.cpp:149-185; the particle's own box unless it shares its Morton
+// code with others) -- without descending the last levels of the pair tree, where nine tenths of
+// its node pairs are (1M-object LEO population, tiles of <= 16 x 16: 6.2e6 node pairs + 3.8e8
+// box tests instead of 6.0e7 node pairs, each of which costs two 96-byte gathers, four box tests
+// and a compaction). TL lanes per tile, lane i holds particle i of the x range and loops over the
+// y range; the hits of a lane are kept as a bit mask and appended, tile by tile, to a buffer in
+// LDS that is flushed to the pair list with one atomic per ~1000 pairs: the pairs of a tile stay
+// together, so the narrow phase's pre-filter finds both trajectory records of consecutive pairs
+// in the same few cache lines.
+constexpr int DT_TILE_WAVES = 4;
+
+// What a lane holds of its tile: the tile, particle i of the longer range ("x") and particle i of
+// the shorter one ("y"; the test is symmetric: the original indices decide who queries whom).
+struct dt_tile_in {
+    std::uint32_t xb, yb, xn, yn, c; // xn >= yn; xn = 0: no tile
+    float4 lbx, ubx, lby, uby;
+    std::uint32_t ix, iy;
+};
+
+CSC_DEV void dt_tile_decode(unsigned long long rec, bool valid, dt_tile_in &t)
+{
+    std::uint32_t xb = static_cast<std::uint32_t>(rec) & (DT_TILE_MAX_N - 1u);
+    std::uint32_t yb = static_cast<std::uint32_t>(rec >> 24) & (DT_TILE_MAX_N - 1u);
+    std::uint32_t xn = (static_cast<std::uint32_t>(rec >> 48) & 15u) + 1u;
+    std::uint32_t yn = (static_cast<std::uint32_t>(rec >> 52) & 15u) + 1u;
+    if (yn > xn) {
+        const std::uint32_t tb = xb, tn = xn;
+        xb = yb;
+        xn = yn;
+        yb = tb;
+        yn = tn;
+    }
+    t.xb = xb;
+    t.yb = yb;
+    t.xn = valid ? xn : 0u;
+    t.yn = valid ? yn : 0u;
+    t.c = valid ? static_cast<std::uint32_t>(rec >> 56) : 0u;
+}
+
+template <int TL>
+__global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_params q)
+{
+    constexpr int TPW = 64 / TL;
+    constexpr std::uint32_t BUF = 64u * TL; // what one batch can yield at most
+    // Staging area of the y particles: the TL slots of a tile, then one slot of padding, so that
+    // the TPW broadcast reads of one instruction (slot j of every tile) fall on distinct banks
+    // (unpadded, the tiles are 128 or 256 bytes apart: the same four banks, a TPW-way conflict;
+    // measured: 41 % of the LDS cycles).
+    constexpr int YS = 64 + TPW;
+    __shared__ float4 s_lb[DT_TILE_WAVES][YS], s_ub[DT_TILE_WAVES][YS];
+    __shared__ std::uint32_t s_info[DT_TILE_WAVES][YS];
+    __shared__ unsigned long long s_buf[DT_TILE_WAVES][BUF];
+    __shared__ std::uint32_t s_fill[DT_TILE_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const std::uint32_t xi = lane % TL, gbase = lane - xi;
+    const std::uint32_t ybase = gbase + lane / TL, yslot = ybase + xi; // (padded staging slots)
+    const std::uint32_t shard = blockIdx.x % DT_SHARDS;
+    const std::uint32_t cnt_raw = q.tile_cnt[shard * DT_CTR_STRIDE];
+    const std::uint32_t cnt = cnt_raw < q.tile_cap ? cnt_raw : q.tile_cap;
+    const unsigned long long *tiles = q.tiles + static_cast<std::size_t>(shard) * q.tile_cap;
+    unsigned long long *pout = q.pairs + static_cast<std::size_t>(shard) * q.pair_cap;
+    std::uint32_t *pair_cnt = q.pair_cnt + shard * DT_CTR_STRIDE;
+    unsigned long long *buf = s_buf[wave];
+    float4 *ylb = s_lb[wave], *yub = s_ub[wave];
+    std::uint32_t *yinfo = s_info[wave];
+    std::uint32_t *fillp = &s_fill[wave];
+
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (lane == 0) {
+        *fillp = 0u;
+    }
+    wave_sync();
+    // The wave's pair buffer -> the pair list of the shard: one atomic, coalesced stores.
+    auto flush = [&](std::uint32_t fill) {
+        std::uint32_t base = 0;
+        if (lane == 0) {
+            base = atomicAdd(pair_cnt, fill);
+            *fillp = 0u;
+        }
+        base = __shfl(base, 0);
+        for (std::uint32_t k = lane; k < fill; k += 64u) {
+            if (base + k < q.pair_cap) {
+                pout[base + k] = buf[k];
+            }
+        }
+        wave_sync();
+    };
+    // Batches of TPW tiles: a contiguous run of the shard's list per workgroup (consecutive tiles
+    // come from neighbouring node pairs: their boxes share cache lines), its waves interleaved.
+    const std::uint64_t step = DT_TILE_WAVES;
+    const std::uint64_t nb_all = (static_cast<std::uint64_t>(cnt) + TPW - 1u) / TPW;
+    const std::uint64_t per_wg = (nb_all + gridDim.x / DT_SHARDS - 1u) / (gridDim.x / DT_SHARDS);
+    const std::uint64_t b0 = static_cast<std::uint64_t>(blockIdx.x / DT_SHARDS) * per_wg;
+    const std::uint64_t nbatch = b0 + per_wg < nb_all ? b0 + per_wg : nb_all;
+    std::uint64_t batch = b0 + wave;
+    if (batch >= nbatch) {
+        return; // (nothing for this wave; in particular no tiles at all)
+    }
+    // (Every load below is unconditional, on a clamped index: loads under a branch would make
+    // the compiler wait for ALL outstanding loads, the prefetched ones included, at the first use.)
+    auto rec_of = [&](std::uint64_t b, bool &valid) {
+        const std::uint64_t t = b * TPW + lane / TL;
+        valid = t < cnt; // (cnt != 0 here)
+        return tiles[valid ? t : cnt - 1u];
+    };
+    auto load_boxes = [&](dt_tile_in &t) {
+        const std::size_t po = static_cast<std::size_t>(t.c) * q.n;
+        const bool xon = xi < t.xn, yon = xi < t.yn;
+        const std::size_t px = po + t.xb + (xon ? xi : 0u), py = po + t.yb + (yon ? xi : 0u);
+        t.lbx = q.slb[px];
+        t.ubx = q.sub[px];
+        t.ix = q.sinfo[px];
+        t.lby = q.slb[py];
+        t.uby = q.sub[py];
+        t.iy = q.sinfo[py];
+    };
+    // One batch: stage the y particles, test, append the hits.
+    auto process = [&](const dt_tile_in &t) {
+        const bool on = xi < t.xn;
+        const bool self = t.xb == t.yb;
+        const std::uint32_t tix = on ? t.ix : 0u, tiy = xi < t.yn ? t.iy : 0u;
+        ylb[yslot] = t.lby;
+        yub[yslot] = t.uby;
+        // The y particles a lane has to look at: [jlo, jhi); of those, the ones that make an
+        // active pair with its x particle (activity flags of either, src/sim_broad_phase.cpp:175-185).
+        const std::uint32_t jlo = self ? xi + 1u : 0u, jhi = on ? t.yn : 0u;
+        std::uint32_t want = (jhi > jlo) ? (((1u << jhi) - 1u) & ~((1u << jlo) - 1u)) : 0u;
+        const unsigned long long yact = __ballot((tiy & (3u << 24)) != 0u);
+        if ((tix & (3u << 24)) == 0u) {
+            want &= static_cast<std::uint32_t>(yact >> gbase);
+        }
+        // A member of a multi-particle leaf anywhere in this batch: the generic test (leaf boxes).
+        const bool anym = __any(((tix | tiy) & SINFO_MULTI) != 0u);
+        if (anym) {
+            yinfo[yslot] = tiy;
+        }
+        wave_sync();
+        std::uint32_t hits = 0;
+        if (!anym) {
+            // Every lane runs every test (the staging area has 64 valid slots); the comparisons
+            // are wave ballots, their conjunction is scalar work.
+            for (std::uint32_t j = 0; j < static_cast<std::uint32_t>(TL); ++j) {
+                if (!__any(j < jhi)) {
+                    break;
+                }
+                const unsigned long long m = bp_overlap_mask(t.lbx, t.ubx, ylb[ybase + j], yub[ybase + j]);
+                hits |= __builtin_amdgcn_inverse_ballot_w64(m) ? (1u << j) : 0u; // (one v_cndmask on the scalar mask)
+            }
+            hits &= want;
+        } else {
+            const std::size_t po = static_cast<std::size_t>(t.c) * q.n, no = static_cast<std::size_t>(t.c) * q.nn_max;
+            float4 llx = t.lbx, lux = t.ubx;
+            if (on && (tix & SINFO_MULTI)) {
+                const std::uint32_t lf = q.sleaf[po + t.xb + xi];
+                llx = q.nlb[no + lf];
+                lux = q.nub[no + lf];
+            }
+            const std::uint32_t ox = tix & 0xffffffu;
+#pragma unroll 1
+            for (std::uint32_t j = 0; j < static_cast<std::uint32_t>(TL); ++j) {
+                if ((want >> j) & 1u) {
+                    const float4 lby = ylb[ybase + j], uby = yub[ybase + j];
+                    const std::uint32_t iy = yinfo[ybase + j];
+                    float4 lly = lby, luy = uby;
+                    if (iy & SINFO_MULTI) {
+                        const std::uint32_t lf = q.sleaf[po + t.yb + j];
+                        lly = q.nlb[no + lf];
+                        luy = q.nub[no + lf];
+                    }
+                    const bool hit = ox < (iy & 0xffffffu) ? bp_overlap(t.lbx, t.ubx, lly, luy) : bp_overlap(lby, uby, llx, lux);
+                    hits |= static_cast<std::uint32_t>(hit) << j;
+                }
+            }
+        }
+        // Append to the wave's buffer (positions from an LDS counter; pairs as (x, y) positions:
+        // the readers of the list order them by original index).
+        const unsigned long long any_hit = __ballot(hits != 0u);
+        if (any_hit != 0ull) {
+            const std::uint32_t fill = *fillp;
+            if (fill + static_cast<std::uint32_t>(__popcll(any_hit)) * TL > BUF) {
+                flush(fill);
+            }
+            if (hits != 0u) {
+                std::uint32_t pos = atomicAdd(fillp, static_cast<std::uint32_t>(__popc(hits)));
+                const unsigned long long rec0 = dt_pair(t.xb + xi, t.yb, t.c);
+                std::uint32_t m = hits;
+                while (m != 0u) {
+                    const std::uint32_t j = static_cast<std::uint32_t>(__ffs(m)) - 1u;
+                    m &= m - 1u;
+                    buf[pos++] = rec0 + (static_cast<unsigned long long>(j) << 28);
+                }
+            }
+        }
+        wave_sync(); // (the staging area is rewritten by the next batch)
+    };
+    // Software pipeline, unrolled by two so that no register moves are needed: the tile of batch
+    // k + 2 and the boxes of batch k + 1 are in flight while batch k is tested.
+    dt_tile_in ta{}, tb{};
+    bool va, vb;
+    unsigned long long ra = rec_of(batch, va);
+    dt_tile_decode(ra, va, ta);
+    load_boxes(ta);
+    unsigned long long rb = rec_of(batch + step, vb);
+    while (batch < nbatch) {
+        dt_tile_decode(rb, vb, tb);
+        load_boxes(tb);
+        ra = rec_of(batch + 2u * step, va);
+        process(ta);
+        batch += step;
+        if (batch >= nbatch) {
+            break;
+        }
+        dt_tile_decode(ra, va, ta);
+        load_boxes(ta);
+        rb = rec_of(batch + 2u * step, vb);
+        process(tb);
+        batch += step;
+    }
+    wave_sync();
+    const std::uint32_t fill = *fillp;
+    if (fill != 0u) {
+        flush(fill);
     }
 }
 

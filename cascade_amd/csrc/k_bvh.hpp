@@ -428,8 +428,12 @@ struct tnode {
 static_assert(sizeof(tnode) == 96, "wide node layout");
 
 // One thread per canonical node; internal nodes fill their record.
+// sinfo / sleaf (for the tile kernel of k_bp_dual.hpp; null = not wanted): per sorted position,
+// orig | act << 24 | (member of a multi-particle leaf) << 26, and for such members the canonical
+// index of their leaf (whose box, not the particle's, is what a query is tested against).
+constexpr std::uint32_t SINFO_MULTI = 1u << 26;
 CSC_GLOBAL __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, const std::uint8_t *active,
-                                                  tnode *tn, std::uint8_t *sact)
+                                                  tnode *tn, std::uint8_t *sact, std::uint32_t *sinfo, std::uint32_t *sleaf)
 {
     const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= b.n_nodes[c]) {
@@ -460,6 +464,23 @@ CSC_GLOBAL __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_
     t.c0 = make_int4(tag0, static_cast<int>(b0), static_cast<int>(b.ne[no + l]), static_cast<int>(o0));
     t.c1 = make_int4(tag1, static_cast<int>(b1), static_cast<int>(b.ne[no + l + 1]), static_cast<int>(o1));
     tn[no + p] = t;
+    if (sinfo != nullptr) {
+        const std::size_t po = static_cast<std::size_t>(c) * b.n;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if ((k ? tag1 : tag0) < 0) {
+                const std::uint32_t lb_ = k ? b1 : b0, le_ = b.ne[no + l + k];
+                const std::uint32_t multi = le_ - lb_ > 1u ? SINFO_MULTI : 0u;
+                for (std::uint32_t m = lb_; m != le_; ++m) {
+                    const std::uint32_t o = vx[m];
+                    sinfo[po + m] = o | (static_cast<std::uint32_t>(active[o] & 3u) << 24) | multi;
+                    if (multi) {
+                        sleaf[po + m] = static_cast<std::uint32_t>(l + k);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // Output of the broad phase: pair blocks of up to PB_SIZE pairs {i, j}. A wave flushes its LDS

@@ -630,7 +630,9 @@ __global__ __launch_bounds__(NP_FLAT_TILE) void k_np_prefilter_flat(const np_par
     if (keep) {
         const std::uint32_t slot = atomicAdd(&q.counters[5], 1u);
         if (slot < q.cand_cap) {
-            q.cand[slot] = make_uint4(q.vidx[co + pa], q.vidx[co + pb], c, 0u);
+            // (i < j; the tile kernel of the broad phase records positions in no particular order)
+            const std::uint32_t oa = q.vidx[co + pa], ob = q.vidx[co + pb];
+            q.cand[slot] = make_uint4(oa < ob ? oa : ob, oa < ob ? ob : oa, c, 0u);
         }
     }
 }

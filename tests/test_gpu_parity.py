@@ -62,6 +62,59 @@ def test_aabb_to_pairs_bit_exact(orc, ctx, n, n_par_ct, same_code):
     check_aabb_to_pairs(orc, ctx, s, len(st))
 
 
+@pytest.mark.parametrize("n_par_ct", [1, 2])
+def test_pairs_with_multi_particle_leaves(orc, ctx, n_par_ct):
+    """Groups of 2..20 particles with identical states (identical boxes -> equal Morton codes ->
+    multi-particle leaves, test/same_morton_code.cpp) among ordinary ones: leaves within the
+    tile limit of k_bp_tiles (leaf boxes instead of particle boxes), leaves beyond it (the
+    traversal's one-by-one path), a third of the particles without activity flags; the pair set
+    stays bit-identical to the oracle's."""
+    from _stage_parity import check_aabb_to_pairs
+
+    rng = np.random.default_rng(5)
+    st = _pop(3000, seed=17)
+    k = 0
+    for g in range(60):
+        size = 2 + g % 19
+        src = int(rng.integers(1500, 3000))
+        st[k : k + size] = st[src]
+        k += size
+    assert k < 1500
+    st[:, 6] = np.where(rng.random(len(st)) < 0.33, 0.0, 1e-7)
+    st = st[rng.permutation(len(st))]
+    s = orc.Sim(st, 0.23, n_par_ct=n_par_ct, min_coll_radius=1e-9)
+    s.step()
+    ca, cj = s.active_flags()
+    assert 0 < int(ca.sum()) < len(st)
+    codes, _ = s.codes(0)
+    _, cnts = np.unique(codes, return_counts=True)
+    assert cnts.max() >= 20 and ((cnts > 1) & (cnts <= 8)).any()  # leaves beyond and within the tile limit
+    check_aabb_to_pairs(orc, ctx, s, len(st))
+
+
+def test_tiles_change_nothing(orc, ctx, monkeypatch):
+    """The pair set with the tile kernel (default), with tiles of 16 and without tiles."""
+    import ctypes as C
+
+    from cascade_amd import _capi
+
+    st = _pop(20000, seed=3)
+    s, _ = _oracle_step(orc, st, 2)
+    ref = [s.bp_pairs(c) for c in range(2)]
+    from _stage_parity import check_aabb_to_pairs
+
+    for tile in ("0", "16", None):
+        if tile is None:
+            monkeypatch.delenv("CASCADE_DT_TILE", raising=False)
+        else:
+            monkeypatch.setenv("CASCADE_DT_TILE", tile)
+        c2 = _capi.Context(0)
+        try:
+            assert check_aabb_to_pairs(orc, c2, s, len(st)) == sum(len(r) for r in ref)
+        finally:
+            c2.close()
+
+
 def _split_rows(tcs, nsub, order):
     """Oracle coefficients [tot][7][21] (particle order) -> the library's CSR layout with the
     rows of particle order[k] stored k-th: (tc_row [n], xyz [tot][64], vr [tot][84], row_perm)
