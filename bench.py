@@ -84,8 +84,11 @@ BYTES = {
     "k_propagate": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28 + 64 * u["nchunks"]),
     "k_np_fex": lambda u: u["np_candidates"] * 1008,
     "k_broad_phase": lambda u: u["bp_nodes_visited"] * 44 + u["pairs"] * 8,
-    # K6 = 44 B x nodes visited + 8 B x pairs; the dual traversal visits two nodes per node pair.
-    "k_bp_dual": lambda u: u["bp_node_pairs"] * 2 * 44 + u["pairs"] * 8,
+    # K6 = 44 B x nodes visited + 8 B x pairs; the dual traversal visits two nodes per node pair
+    # and ends in tiles (8 B each) when k_bp_tiles is on, in pairs otherwise.
+    "k_bp_dual": lambda u: u["bp_node_pairs"] * 2 * 44 + (u["bp_tiles"] * 8 if u["bp_tiles"] else u["pairs"] * 8),
+    # every tile record once, every particle's box + flags once (36 B; the tiles share them), every pair out
+    "k_bp_tiles": lambda u: u["bp_tiles"] * 8 + u["n"] * u["nchunks"] * 36 + u["pairs"] * 8,
     # single-pass rows (every object's substep rows written while it is integrated)
     "k_propagate_rows": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28 + 64 * u["nchunks"]) + u["substeps"] * (1176 + 16),
     # every pair record read once, every trajectory record read once (the pairs of a chunk share them)
@@ -255,6 +258,7 @@ def main():
         stored_substeps=s.last_stored_objects * max(1.0, s.last_total_substeps / N),
         sort_keys=N * args.n_par_ct,
         bp_node_pairs=s.last_bp_node_pairs,
+        bp_tiles=s.last_bp_tiles,
         bp_nodes_visited=0,
     )
     if dom == "k_broad_phase":

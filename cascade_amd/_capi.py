@@ -109,6 +109,7 @@ SYMBOLS = {
     "csc_profile_get": (_i32, [_vp, C.c_char_p, _sz]),
     "csc_propagate": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 10),
     "csc_broad_phase_node_pairs": (C.c_uint64, [_vp]),
+    "csc_broad_phase_tiles": (C.c_uint64, [_vp]),
     "csc_narrow_phase_view": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "csc_propagate_rows": (_i32, [_vp, C.POINTER(PropCfg), _u32] + [_vp] * 10 + [_u32] + [_vp] * 4),
     "csc_propagate_summary": (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(PropSummary)]),

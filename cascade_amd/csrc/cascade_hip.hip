@@ -1480,18 +1480,33 @@ int csc_morton_encode(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d
 static int radix_sort(csc_ctx *ctx, uint32_t n, uint32_t nseg, int nbits, uint64_t *keys_a, uint32_t *vals_a,
                       bool vals_iota, uint64_t *keys_b, uint32_t *vals_b, uint64_t **keys_res, uint32_t **vals_res)
 {
-    const unsigned nblocks = cdiv(n, csc::RS_TILE);
+    // 2048 keys per block; 8192 was measured and is slower even at 8M keys
+    // (scatter 2.86 against 2.00 ms per 8 passes: the ranking chain of a wave is four times as
+    // long and fewer waves hide it; the writes were not the limit).
+    const char *ei = std::getenv("CASCADE_RS_ITEMS");
+    const bool big = ei && std::atoi(ei) >= csc::RS_ITEMS_BIG;
+    const unsigned nblocks = cdiv(n, csc::RS_BLOCK * (big ? csc::RS_ITEMS_BIG : csc::RS_ITEMS));
     CSC_BUF(d_hist, uint32_t, "rs_hist", static_cast<size_t>(nseg) * csc::RS_BINS * nblocks);
     CSC_BUF(d_btot, uint32_t, "rs_bin_tot", static_cast<size_t>(nseg) * csc::RS_BINS);
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
     bool iota = vals_iota;
     for (int shift = 0; shift < nbits; shift += 8) {
-        KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin, n, shift,
-                           d_hist, nblocks));
+        if (big) {
+            KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist<csc::RS_ITEMS_BIG>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream,
+                                                kin, n, shift, d_hist, nblocks));
+        } else {
+            KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist<csc::RS_ITEMS>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
+                                                n, shift, d_hist, nblocks));
+        }
         KT("k_rs_scan", hipLaunchKernelGGL(csc::k_rs_scan, dim3(csc::RS_BINS, nseg), dim3(256), 0, ctx->stream, d_hist, nblocks, d_btot));
-        KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
-                           iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
+        if (big) {
+            KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter<csc::RS_ITEMS_BIG>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0,
+                                                   ctx->stream, kin, iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
+        } else {
+            KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter<csc::RS_ITEMS>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream,
+                                                   kin, iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
+        }
         CSC_LAUNCH_CHECK();
         std::swap(kin, kout);
         std::swap(vin, vout);
@@ -1643,6 +1658,11 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
 uint64_t csc_broad_phase_node_pairs(csc_ctx *ctx)
 {
     return ctx->bp_node_pairs;
+}
+
+uint64_t csc_broad_phase_tiles(csc_ctx *ctx)
+{
+    return ctx->bp_tiles;
 }
 
 int csc_set_chunk_map(csc_ctx *ctx, uint32_t first, uint32_t nchunks_global)
@@ -1880,6 +1900,7 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     ctx->bvh_packed = true;
     ctx->bp_flat = false;
     ctx->bp_node_pairs = 0;
+    ctx->bp_tiles = 0;
     if (dual) {
         return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, tile_max, n_pairs);
     }

@@ -374,6 +374,7 @@ PYBIND11_MODULE(core, m)
         .def_property_readonly("last_np_attempts", [](const sim &s) { return s.get_step_stats().np_attempts; })
         .def_property_readonly("last_propagated", [](const sim &s) { return s.get_step_stats().propagated; })
         .def_property_readonly("last_bp_node_pairs", [](const sim &s) { return s.get_step_stats().bp_node_pairs; })
+        .def_property_readonly("last_bp_tiles", [](const sim &s) { return s.get_step_stats().bp_tiles; })
         .def_property_readonly("last_total_substeps", [](const sim &s) { return s.get_step_stats().total_substeps; })
         .def_property_readonly("last_nchunks", [](const sim &s) { return s.get_step_stats().nchunks; })
         .def_property_readonly("last_collisions",

@@ -1586,6 +1586,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
 
     d.stats.bp_pairs = npairs;
     d.stats.bp_node_pairs = have_chunks ? csc_broad_phase_node_pairs(ctx) : 0u;
+    d.stats.bp_tiles = have_chunks ? csc_broad_phase_tiles(ctx) : 0u;
     d.stats.np_candidates = have_chunks ? csc_narrow_phase_candidates(ctx) : 0u;
     d.stats.np_attempts = have_chunks ? np_attempts + csc_narrow_phase_attempts(ctx) : 0u;
     d.stats.chunk_first = c0;

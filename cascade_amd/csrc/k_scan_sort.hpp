@@ -144,15 +144,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const std::uint32_t *
 // ---------------------------------------------------------------------------
 constexpr int RS_BLOCK = 256;
 constexpr int RS_WAVES = RS_BLOCK / 64;
+// Keys per thread: 8 (2048 per block). 32 (8192 per block: a quarter of the per-block counters,
+// is kept for measurements only (CASCADE_RS_ITEMS=16): 8192 per block was slower at 1M and 8M keys.
 constexpr int RS_ITEMS = 8;
-constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per block
+constexpr int RS_ITEMS_BIG = 16;
 constexpr int RS_BINS = 256;
 
 // block_hist layout: [chunk][bin][nblocks] (so that one linear exclusive scan per chunk
 // gives the global offset of (bin, block)).
+template <int ITEMS>
 __global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const std::uint64_t *keys, std::uint32_t n, int shift,
                                                       std::uint32_t *block_hist, std::uint32_t nblocks)
 {
+    constexpr int RS_ITEMS = ITEMS, RS_TILE = RS_BLOCK * ITEMS;
     __shared__ std::uint32_t h[RS_BINS];
     const std::uint32_t chunk = blockIdx.y;
     keys += static_cast<std::size_t>(chunk) * n;
@@ -195,11 +199,13 @@ __global__ __launch_bounds__(256) void k_rs_scan(std::uint32_t *block_hist, std:
 }
 
 // vals_in == nullptr means "iota" (first pass of an index sort).
+template <int ITEMS>
 __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const std::uint64_t *keys_in, const std::uint32_t *vals_in,
                                                          std::uint64_t *keys_out, std::uint32_t *vals_out,
                                                          std::uint32_t n, int shift, const std::uint32_t *block_hist,
                                                          std::uint32_t nblocks, const std::uint32_t *bin_tot)
 {
+    constexpr int RS_ITEMS = ITEMS, RS_TILE = RS_BLOCK * ITEMS;
     __shared__ std::uint32_t cnt[RS_WAVES][RS_BINS];
     __shared__ std::uint64_t scan_lds[RS_BLOCK / 64 + 1];
     const std::uint32_t chunk = blockIdx.y;
@@ -249,16 +255,28 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const std::uint64_t *ke
         rank[it] = pre + static_cast<std::uint32_t>(__popcll(peers & lt_mask));
     }
     __syncthreads();
-    // Turn the per-wave counts into per-wave bases: global offset of (digit, block) plus the
-    // counts of the preceding waves of this block.
+    // Reorder the tile by digit in LDS, then write it out in tile order: the keys of one digit
+    // leave the block as ONE run of consecutive addresses (written by consecutive threads) instead
+    // of one 8-byte store per key into ~64 different cache lines per wave instruction (measured:
+    // the partial-line write transactions, not the bytes, bounded this kernel).
+    __shared__ std::uint64_t skey[RS_BLOCK * ITEMS];
+    __shared__ std::uint32_t sval[RS_BLOCK * ITEMS];
+    __shared__ std::uint32_t gdst[RS_BINS];
     {
         const int d = threadIdx.x; // RS_BLOCK == RS_BINS
-        // Start of digit d = keys with a smaller digit (scan of the bin totals) + keys with digit d
-        // in earlier blocks.
+        std::uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            tot += cnt[w][d];
+        }
+        // Start of digit d within the tile, and in the output: keys with a smaller digit (scan of
+        // the bin totals) + keys with digit d in earlier blocks.
         std::uint64_t tot_unused;
+        const std::uint32_t dstart = static_cast<std::uint32_t>(block_exclusive_scan_u64(tot, &tot_unused, scan_lds));
         const std::uint32_t bin_base
             = static_cast<std::uint32_t>(block_exclusive_scan_u64(bin_tot[chunk * RS_BINS + d], &tot_unused, scan_lds));
-        std::uint32_t run = bin_base + goff[static_cast<std::size_t>(d) * nblocks + blockIdx.x];
+        gdst[d] = bin_base + goff[static_cast<std::size_t>(d) * nblocks + blockIdx.x] - dstart; // (mod 2^32; + tile position below)
+        std::uint32_t run = dstart;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) {
             const std::uint32_t c = cnt[w][d];
@@ -272,9 +290,22 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const std::uint64_t *ke
         const std::uint32_t idx = wbase + it * 64 + lane;
         if (idx < n) {
             const std::uint32_t d = static_cast<std::uint32_t>(key[it] >> shift) & 0xffu;
-            const std::uint32_t pos = cnt[wid][d] + rank[it];
-            keys_out[pos] = key[it];
-            vals_out[pos] = vals_in ? vals_in[idx] : idx;
+            const std::uint32_t lp = cnt[wid][d] + rank[it];
+            skey[lp] = key[it];
+            sval[lp] = vals_in ? vals_in[idx] : idx;
+        }
+    }
+    __syncthreads();
+    const std::uint32_t tile_n = n - blockIdx.x * RS_TILE < static_cast<std::uint32_t>(RS_TILE) ? n - blockIdx.x * RS_TILE : RS_TILE;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const std::uint32_t e = it * RS_BLOCK + threadIdx.x;
+        if (e < tile_n) {
+            const std::uint64_t k = skey[e];
+            const std::uint32_t d = static_cast<std::uint32_t>(k >> shift) & 0xffu;
+            const std::uint32_t pos = gdst[d] + e;
+            keys_out[pos] = k;
+            vals_out[pos] = sval[e];
         }
     }
 }

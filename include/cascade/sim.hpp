@@ -208,6 +208,7 @@ public:
     struct step_stats {
         std::uint64_t bp_pairs = 0;       // AABB pairs found by the broad phase
         std::uint64_t bp_node_pairs = 0;  // node pairs expanded by the broad phase's dual traversal
+        std::uint64_t bp_tiles = 0;       // ... and the tiles (small node pairs tested directly) it ended in
         std::uint64_t propagated = 0;     // particles this process integrated in the first pass
         std::uint64_t np_candidates = 0;  // pairs that reached the polynomial narrow phase
         std::uint64_t total_substeps = 0; // Taylor substeps of all particles

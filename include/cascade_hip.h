@@ -304,6 +304,9 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
  * k_bp_dual.hpp: each reads two wide node records and tests up to four box pairs); 0 when the
  * per-particle walk was used. For the roofline accounting. */
 uint64_t csc_broad_phase_node_pairs(csc_ctx *ctx);
+/* Tiles of the last csc_broad_phase: node pairs of at most 8 x 8 particles at which the dual
+ * traversal stopped and whose particle pairs k_bp_tiles tested directly (0: none). */
+uint64_t csc_broad_phase_tiles(csc_ctx *ctx);
 /* Multi-GPU query sharding (no counterpart in the reference, which is single-process): every
  * process holds the whole tree, and csc_broad_phase walks it only for the query groups dealt
  * to `rank` (runs of 16 groups of 64 Morton-consecutive particles, round-robin over `nranks`).
