@@ -43,7 +43,9 @@ struct conj_rec {
 static_assert(sizeof(conj_rec) == 128, "conjunction layout");
 
 constexpr int NP_FLAT_SHARDS = 32; // = DT_SHARDS of k_bp_dual.hpp
-constexpr unsigned NP_FLAT_TILE = 256; // pairs per workgroup of k_np_prefilter_flat (4 waves: a quarter of the workgroup launches)
+// k_np_prefilter_flat: 256 threads, 4 pairs each, workgroups looping over the tiles.
+constexpr unsigned NP_FLAT_BLOCK = 256, NP_FLAT_PPT = 4;
+constexpr unsigned NP_FLAT_TILE = NP_FLAT_BLOCK * NP_FLAT_PPT; // pairs per workgroup
 
 struct np_params {
     std::uint32_t n;       // particles
@@ -71,6 +73,7 @@ struct np_params {
     std::uint32_t flat_cap;
     std::uint32_t flat_cnt[NP_FLAT_SHARDS];          // pairs of each list
     std::uint32_t flat_tile_off[NP_FLAT_SHARDS + 1]; // first tile (= workgroup, NP_FLAT_TILE pairs) of each list
+    std::uint32_t flat_xcd_run;                      // consecutive tiles handled by the same XCD (0: dispatch order)
     const std::uint32_t *vidx;    // [C][n] sorted position -> original index
     const float4 *srt_recs;       // [C][n][4] sampled-trajectory records in sorted order
     double thr_extra;             // conjunction threshold (0 when conjunctions are not tracked)
@@ -547,16 +550,11 @@ CSC_DEV double np_rsum2(const np_params &q, std::uint32_t pi, std::uint32_t pj)
 // (used to check that the filter does not change any result).
 // The geometric exclusion test for the particles at sorted positions pa, pb of the chunk whose
 // arrays start at offset co. Returns false when the pair can be dropped.
-CSC_DEV bool np_prefilter_keep(const np_params &q, std::size_t co, std::uint32_t pa, std::uint32_t pb)
+// The test proper: the sample differences d_s = a_s - b_s, s = 0..4, and the two radii.
+CSC_DEV bool np_prefilter_core(const float (&dx)[5], const float (&dy)[5], const float (&dz)[5], float thr_extra, float deva,
+                               float devb)
 {
-    const float4 *ra = q.srt_recs + (co + pa) * 4u, *rb = q.srt_recs + (co + pb) * 4u;
-    const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
-    const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
-    // Sample differences d_s = a_s - b_s, s = 0..4 (x, y, z).
-    const float dx[5] = {a0.x - b0.x, a0.w - b0.w, a1.z - b1.z, a2.y - b2.y, a3.x - b3.x};
-    const float dy[5] = {a0.y - b0.y, a1.x - b1.x, a1.w - b1.w, a2.z - b2.z, a3.y - b3.y};
-    const float dz[5] = {a0.z - b0.z, a1.y - b1.y, a2.x - b2.x, a2.w - b2.w, a3.z - b3.z};
-    const float thr = (static_cast<float>(q.thr_extra) + a3.w + b3.w) * 1.000002f;
+    const float thr = (thr_extra + deva + devb) * 1.000002f;
     const float thr2 = thr * thr * 1.000002f;
     bool keep = !(thr2 < __builtin_huge_valf()); // invalid record (dev = +inf) or overflow: never excluded
 #pragma unroll
@@ -575,6 +573,18 @@ CSC_DEV bool np_prefilter_keep(const np_params &q, std::size_t co, std::uint32_t
         keep = keep || !(m2 > thr2);
     }
     return keep;
+}
+
+CSC_DEV bool np_prefilter_keep(const np_params &q, std::size_t co, std::uint32_t pa, std::uint32_t pb)
+{
+    const float4 *ra = q.srt_recs + (co + pa) * 4u, *rb = q.srt_recs + (co + pb) * 4u;
+    const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
+    const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
+    // Sample differences d_s = a_s - b_s, s = 0..4 (x, y, z).
+    const float dx[5] = {a0.x - b0.x, a0.w - b0.w, a1.z - b1.z, a2.y - b2.y, a3.x - b3.x};
+    const float dy[5] = {a0.y - b0.y, a1.x - b1.x, a1.w - b1.w, a2.z - b2.z, a3.y - b3.y};
+    const float dz[5] = {a0.z - b0.z, a1.y - b1.y, a2.x - b2.x, a2.w - b2.w, a3.z - b3.z};
+    return np_prefilter_core(dx, dy, dz, static_cast<float>(q.thr_extra), a3.w, b3.w);
 }
 
 template <bool FILTER>
@@ -604,36 +614,101 @@ __global__ __launch_bounds__(64) void k_np_prefilter(const np_params q)
 // The same over the flat pair lists of the dual traversal (k_bp_dual.hpp): NP_FLAT_SHARDS lists
 // of packed pairs pos_a | pos_b << 28 | chunk << 56; workgroup w handles NP_FLAT_TILE pairs of the shard
 // whose tile range [flat_tile_off[s], flat_tile_off[s + 1]) contains w.
+// Candidates are appended through a buffer in LDS and one device atomic per flush: one atomic per
+// candidate on the list's counter serialises at ~10 ns each (same address), which WAS this
+// kernel's time: 0.32 ms for 27 k candidates, 4.3 ms for 424 k (1M objects, 1 and 8 chunks),
+// whatever the record size (a 32-byte quantised copy of the records, tested first, changed
+// nothing and was removed again) or the number of pairs in flight per lane. Since then: 0.26 and
+// 2.5 ms, the rate at which L1 looks up the 8 x 64 cache lines of a wave's record loads.
+constexpr unsigned NP_FLAT_CBUF = 2 * NP_FLAT_TILE; // flushed before a tile when more than half full
+
 template <bool FILTER>
-__global__ __launch_bounds__(NP_FLAT_TILE) void k_np_prefilter_flat(const np_params q)
+__global__ __launch_bounds__(NP_FLAT_BLOCK) void k_np_prefilter_flat(const np_params q)
 {
-    const std::uint32_t wg = blockIdx.x;
-    int s = 0;
-    while (s + 1 < NP_FLAT_SHARDS && wg >= q.flat_tile_off[s + 1]) {
-        ++s;
+    __shared__ uint4 s_cand[NP_FLAT_CBUF];
+    __shared__ std::uint32_t s_n, s_base;
+    if (threadIdx.x == 0) {
+        s_n = 0;
     }
-    const std::uint32_t t = (wg - q.flat_tile_off[s]) * NP_FLAT_TILE + threadIdx.x;
-    if (t >= q.flat_cnt[s]) {
-        return;
-    }
-    const unsigned long long rec = q.flat_pairs[static_cast<std::size_t>(s) * q.flat_cap + t];
-    const std::uint32_t pa = static_cast<std::uint32_t>(rec) & 0xfffffffu, pb = static_cast<std::uint32_t>(rec >> 28) & 0xfffffffu;
-    const std::uint32_t c = static_cast<std::uint32_t>(rec >> 56);
-    if (c >= q.nchunks) {
-        return;
-    }
-    const std::size_t co = static_cast<std::size_t>(c) * q.n;
-    bool keep = true;
-    if constexpr (FILTER) {
-        keep = np_prefilter_keep(q, co, pa, pb);
-    }
-    if (keep) {
-        const std::uint32_t slot = atomicAdd(&q.counters[5], 1u);
-        if (slot < q.cand_cap) {
-            // (i < j; the tile kernel of the broad phase records positions in no particular order)
-            const std::uint32_t oa = q.vidx[co + pa], ob = q.vidx[co + pb];
-            q.cand[slot] = make_uint4(oa < ob ? oa : ob, oa < ob ? ob : oa, c, 0u);
+    __syncthreads();
+    auto flush = [&]() { // (whole workgroup)
+        const std::uint32_t nb = s_n;
+        if (threadIdx.x == 0 && nb != 0u) {
+            s_base = atomicAdd(&q.counters[5], nb);
         }
+        __syncthreads();
+        const std::uint32_t base = s_base;
+        for (std::uint32_t k = threadIdx.x; k < nb; k += NP_FLAT_BLOCK) {
+            if (base + k < q.cand_cap) {
+                q.cand[base + k] = s_cand[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_n = 0;
+        }
+        __syncthreads();
+    };
+    const std::uint32_t ntiles = q.flat_tile_off[NP_FLAT_SHARDS];
+    for (std::uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        std::uint32_t wg = tile;
+        if (q.flat_xcd_run != 0u) {
+            // Workgroups are dealt to the 8 XCDs round-robin: give each XCD runs of consecutive tiles
+            // of the list, so that its L2 sees one neighbourhood of trajectory records at a time.
+            const std::uint32_t span = 8u * q.flat_xcd_run, full = (ntiles / span) * span;
+            if (wg < full) {
+                const std::uint32_t r = wg % span;
+                wg = (wg / span) * span + (r % 8u) * q.flat_xcd_run + r / 8u;
+            }
+        }
+        int s = 0;
+        while (s + 1 < NP_FLAT_SHARDS && wg >= q.flat_tile_off[s + 1]) {
+            ++s;
+        }
+        const std::uint32_t cnt = q.flat_cnt[s]; // (> 0: the shard has a tile)
+        const std::uint32_t tb = (wg - q.flat_tile_off[s]) * NP_FLAT_TILE + threadIdx.x;
+        const unsigned long long *list = q.flat_pairs + static_cast<std::size_t>(s) * q.flat_cap;
+        // All loads of the NP_FLAT_PPT pairs of a lane are issued before the first use (clamped
+        // indices, no branches in between).
+        unsigned long long rec[NP_FLAT_PPT];
+        bool keep[NP_FLAT_PPT];
+#pragma unroll
+        for (unsigned k = 0; k < NP_FLAT_PPT; ++k) {
+            const std::uint32_t t = tb + k * NP_FLAT_BLOCK;
+            keep[k] = t < cnt;
+            rec[k] = list[keep[k] ? t : cnt - 1u];
+        }
+        std::uint32_t pa[NP_FLAT_PPT], pb[NP_FLAT_PPT], c[NP_FLAT_PPT];
+#pragma unroll
+        for (unsigned k = 0; k < NP_FLAT_PPT; ++k) {
+            pa[k] = static_cast<std::uint32_t>(rec[k]) & 0xfffffffu;
+            pb[k] = static_cast<std::uint32_t>(rec[k] >> 28) & 0xfffffffu;
+            c[k] = static_cast<std::uint32_t>(rec[k] >> 56);
+            // (chunk dropped by a terminal-event shrink of the superstep, src/sim_narrow_phase.cpp:560)
+            keep[k] = keep[k] && c[k] < q.nchunks;
+        }
+#pragma unroll
+        for (unsigned k = 0; k < NP_FLAT_PPT; ++k) {
+            if (keep[k]) {
+                const std::size_t co = static_cast<std::size_t>(c[k]) * q.n;
+                bool kk = true;
+                if constexpr (FILTER) {
+                    kk = np_prefilter_keep(q, co, pa[k], pb[k]);
+                }
+                if (kk) {
+                    // (i < j; the tile kernel of the broad phase records positions in no particular order)
+                    const std::uint32_t oa = q.vidx[co + pa[k]], ob = q.vidx[co + pb[k]];
+                    s_cand[atomicAdd(&s_n, 1u)] = make_uint4(oa < ob ? oa : ob, oa < ob ? ob : oa, c[k], 0u);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_n > NP_FLAT_TILE) { // (uniform: s_n is stable between the barriers)
+            flush();
+        }
+    }
+    if (s_n != 0u) {
+        flush();
     }
 }
 
