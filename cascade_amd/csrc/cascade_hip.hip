@@ -1708,7 +1708,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
     // until the empty ones of the small levels cost more); 128 for small populations.
     // CASCADE_DT_GRID overrides (measurements).
     const unsigned per_shard = std::getenv("CASCADE_DT_GRID") ? std::max(1, std::atoi(std::getenv("CASCADE_DT_GRID")))
-                                                              : (static_cast<uint64_t>(n) * nchunks >= 200000u ? 512u : 128u);
+                                                              : (static_cast<uint64_t>(n) * nchunks >= 200000u ? 16384u / DT_SHARDS : 4096u / DT_SHARDS);
     const unsigned grid = DT_SHARDS * per_shard;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -1785,7 +1785,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         }
         if (tile_max != 0u) {
             // Workgroups stride over the tile batches of their shard: 8 per CU fill the chip.
-            const unsigned tg = DT_SHARDS * (static_cast<uint64_t>(n) * nchunks >= 200000u ? 64u : 8u);
+            const unsigned tg = static_cast<uint64_t>(n) * nchunks >= 200000u ? 2048u : 256u;
             if (tile_max <= 8u) {
                 KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
             } else {

@@ -19,3 +19,4 @@ echo "write pass done"
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "plain bench done"
 find $OUT -name '*.csv' | head -20
+bash profiles/pmc_tiles.sh $TAG > $OUT/pmc_tiles.log 2>&1 && echo "pmc tiles done"
