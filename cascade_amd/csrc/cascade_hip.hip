@@ -93,6 +93,7 @@ struct csc_ctx {
     const unsigned long long *bp_flat_pairs = nullptr;
     uint32_t bp_flat_cap = 0;
     uint32_t bp_flat_cnt[csc::DT_SHARDS] = {};
+    bool bvh_canonical = false; // the nodes of ctx->bvh are in the reference's order (csc_bvh_export)
     uint32_t dt_fr_cap = 0, dt_pair_cap = 0, dt_tile_cap = 0;
     uint64_t bp_tiles = 0; // tiles of the last dual traversal
     uint64_t bp_node_pairs = 0;
@@ -1549,8 +1550,11 @@ int csc_sort_gather(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *
 
 // ---- K5 --------------------------------------------------------------------------------
 
-int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_srt_codes, const float *d_srt_lbs,
-                  const float *d_srt_ubs)
+// canonical: the reference's node order (needed by csc_bvh_export only); otherwise the nodes are
+// numbered straight from the Karras ids (k_bvh_emit_fast) and the depth / sort / renumber passes
+// are skipped. CASCADE_BVH_CANONICAL=1 forces the former (measurements, tests).
+static int bvh_build_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_srt_codes, const float *d_srt_lbs,
+                          const float *d_srt_ubs, bool canonical)
 {
     if (n == 0u || nchunks == 0u) {
         return ctx->invalid("empty BVH input");
@@ -1611,17 +1615,21 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     }
     KT("k_bvh_run_start", hipLaunchKernelGGL(csc::k_bvh_run_start, gp, blk, 0, ctx->stream, b));
     KT("k_bvh_karras", hipLaunchKernelGGL(csc::k_bvh_karras, gp, blk, 0, ctx->stream, b));
-    KT("k_bvh_depth", hipLaunchKernelGGL(csc::k_bvh_depth, gn, blk, 0, ctx->stream, b));
-    KT("k_bvh_level_off", hipLaunchKernelGGL(csc::k_bvh_level_off, dim3(nchunks), dim3(64), 0, ctx->stream, b));
-    CSC_LAUNCH_CHECK();
-    uint64_t *kres;
-    uint32_t *vres;
-    if (const int rc = radix_sort(ctx, nn_max, nchunks, b.begin_bits + 8, b.skey_a, b.sval_a, true, b.skey_b,
-                                  b.sval_b, &kres, &vres)) {
-        return rc;
+    if (canonical) {
+        KT("k_bvh_depth", hipLaunchKernelGGL(csc::k_bvh_depth, gn, blk, 0, ctx->stream, b));
+        KT("k_bvh_level_off", hipLaunchKernelGGL(csc::k_bvh_level_off, dim3(nchunks), dim3(64), 0, ctx->stream, b));
+        CSC_LAUNCH_CHECK();
+        uint64_t *kres;
+        uint32_t *vres;
+        if (const int rc = radix_sort(ctx, nn_max, nchunks, b.begin_bits + 8, b.skey_a, b.sval_a, true, b.skey_b,
+                                      b.sval_b, &kres, &vres)) {
+            return rc;
+        }
+        KT("k_bvh_newidx", hipLaunchKernelGGL(csc::k_bvh_newidx, gn, blk, 0, ctx->stream, b, vres));
+        KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit, gn, blk, 0, ctx->stream, b, vres));
+    } else {
+        KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit_fast, gn, blk, 0, ctx->stream, b));
     }
-    KT("k_bvh_newidx", hipLaunchKernelGGL(csc::k_bvh_newidx, gn, blk, 0, ctx->stream, b, vres));
-    KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit, gn, blk, 0, ctx->stream, b, vres));
     // Bottom-up refit in one launch (arrival counters start from zero).
     CSC_HIP(hipMemsetAsync(b.visit, 0, cnn * sizeof(uint32_t), ctx->stream));
     KT("k_bvh_refit", hipLaunchKernelGGL(csc::k_bvh_refit, gn, blk, 0, ctx->stream, b));
@@ -1630,13 +1638,29 @@ int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_
     ctx->bvh_packed = false;
     ctx->bvh_n = n;
     ctx->bvh_chunks = nchunks;
+    ctx->bvh_canonical = canonical;
     return CSC_OK;
+}
+
+int csc_bvh_build(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint64_t *d_srt_codes, const float *d_srt_lbs,
+                  const float *d_srt_ubs)
+{
+    const char *e = std::getenv("CASCADE_BVH_CANONICAL");
+    return bvh_build_impl(ctx, n, nchunks, d_srt_codes, d_srt_lbs, d_srt_ubs, e && std::atoi(e) != 0);
 }
 
 int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t cap, uint64_t *n_nodes)
 {
     if (chunk >= ctx->bvh_chunks) {
         return ctx->invalid("invalid chunk index");
+    }
+    if (!ctx->bvh_canonical) {
+        // The reference's node order: built now, from the inputs of the last csc_bvh_build (which
+        // the caller must not have overwritten since).
+        if (const int rc = bvh_build_impl(ctx, ctx->bvh_n, ctx->bvh_chunks, ctx->bvh.codes, reinterpret_cast<const float *>(ctx->bvh.slb),
+                                          reinterpret_cast<const float *>(ctx->bvh.sub), true)) {
+            return rc;
+        }
     }
     uint32_t nn = 0;
     CSC_HIP(hipMemcpyAsync(&nn, ctx->bvh.n_nodes + chunk, sizeof(nn), hipMemcpyDeviceToHost, ctx->stream));

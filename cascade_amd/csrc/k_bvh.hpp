@@ -280,6 +280,68 @@ CSC_GLOBAL __launch_bounds__(256) void k_bvh_emit(bvh_bufs b, const std::uint32_
     b.nsplit[no + p] = split;
 }
 
+// Traversal order. The reference's node order (level by level, each level by `begin`) is what
+// csc_bvh_export must produce, but nothing on the path from the tree to the pairs depends on
+// it: the traversals need the topology, the boxes and siblings next to each other. The depths,
+// the radix sort by (depth, begin) and the renumbering are therefore left to the export, and
+// the build numbers the nodes straight from the Karras ids: the root is 0 and the children of
+// internal Karras node i are 2 i + 1 and 2 i + 2 (a bijection onto [0, 2 M - 1)). Same tree,
+// same boxes, same pair set (tests/test_gpu_parity.py runs every stage-parity case both ways).
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_emit_fast(bvh_bufs b)
+{
+    const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    const std::uint32_t nn = b.n_nodes[c];
+    if (p >= nn) {
+        return;
+    }
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
+    const std::size_t po = static_cast<std::size_t>(c) * b.n;
+    const std::uint32_t M = (nn + 1u) / 2u;
+    const std::uint32_t *rs = b.run_start + static_cast<std::size_t>(c) * (b.n + 1u);
+    // Karras id of node p and of its parent.
+    const std::int32_t kp = p == 0u ? -1 : static_cast<std::int32_t>((p - 1u) >> 1);
+    const std::uint32_t id = p == 0u ? 0u : static_cast<std::uint32_t>(((p - 1u) & 1u) ? b.k_right[po + kp] : b.k_left[po + kp]);
+    std::int32_t parent = -1;
+    if (kp > 0) {
+        const std::int32_t kpp = b.k_parent[no + kp];
+        parent = 2 * kpp + 1 + (b.k_right[po + kpp] == kp ? 1 : 0);
+    } else if (kp == 0) {
+        parent = 0;
+    }
+    const int init_split = kp < 0 ? 0 : b.k_delta[po + kp] + 1;
+    const float finf = __builtin_huge_valf();
+    std::uint32_t begin, end;
+    std::int32_t left;
+    int split;
+    float4 lb = make_float4(finf, finf, finf, finf), ub = make_float4(-finf, -finf, -finf, -finf);
+    if (id < M - 1u) {
+        begin = rs[b.k_first[po + id]];
+        end = rs[b.k_last[po + id] + 1u];
+        left = static_cast<std::int32_t>(2u * id + 1u);
+        split = b.k_delta[po + id];
+    } else {
+        const std::uint32_t r = id - (M - 1u);
+        begin = rs[r];
+        end = rs[r + 1u];
+        left = -1;
+        split = (end - begin > 1u && init_split <= 63) ? 63 : init_split;
+        const float4 *slb = b.slb + po, *sub = b.sub + po;
+        for (std::uint32_t k = begin; k < end; ++k) {
+            const float4 l4 = slb[k], u4 = sub[k];
+            lb = make_float4(fminf_std(lb.x, l4.x), fminf_std(lb.y, l4.y), fminf_std(lb.z, l4.z), fminf_std(lb.w, l4.w));
+            ub = make_float4(fmaxf_std(ub.x, u4.x), fmaxf_std(ub.y, u4.y), fmaxf_std(ub.z, u4.z), fmaxf_std(ub.w, u4.w));
+        }
+    }
+    b.nb[no + p] = begin;
+    b.ne[no + p] = end;
+    b.npar[no + p] = parent;
+    b.nleft[no + p] = left;
+    b.nlb[no + p] = lb;
+    b.nub[no + p] = ub;
+    b.ndepth[no + p] = 0u;
+    b.nsplit[no + p] = split;
+}
+
 // Internal-node AABBs, bottom-up in ONE launch (replaces the level-by-level loop of
 // src/sim_bvh.cpp:411-485). One thread per leaf climbs towards the root; at every internal
 // node the first arriving child stops, the second one (both subtrees final) forms the union of

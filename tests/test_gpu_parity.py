@@ -92,6 +92,30 @@ def test_pairs_with_multi_particle_leaves(orc, ctx, n_par_ct):
     check_aabb_to_pairs(orc, ctx, s, len(st))
 
 
+def test_tree_order_changes_nothing(orc, monkeypatch):
+    """The broad phase on the tree as the build numbers it (straight from the Karras ids) and on
+    the tree in the reference's node order (CASCADE_BVH_CANONICAL=1): same pair set; the export is
+    byte-identical to the oracle's tree either way (check_aabb_to_pairs)."""
+    from cascade_amd import _capi
+
+    from _stage_parity import check_aabb_to_pairs
+
+    st = _pop(5003, seed=11, same_code=True)
+    s, _ = _oracle_step(orc, st, 2)
+    counts = []
+    for canon in ("1", None):
+        if canon is None:
+            monkeypatch.delenv("CASCADE_BVH_CANONICAL", raising=False)
+        else:
+            monkeypatch.setenv("CASCADE_BVH_CANONICAL", canon)
+        c2 = _capi.Context(0)
+        try:
+            counts.append(check_aabb_to_pairs(orc, c2, s, len(st)))
+        finally:
+            c2.close()
+    assert counts[0] == counts[1] == sum(len(s.bp_pairs(c)) for c in range(2))
+
+
 def test_tiles_change_nothing(orc, ctx, monkeypatch):
     """The pair set with the tile kernel (default), with tiles of 16 and without tiles."""
     import ctypes as C
