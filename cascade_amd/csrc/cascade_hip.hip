@@ -387,61 +387,155 @@ __host__ __device__ inline void shard_block(uint32_t nchunks, uint32_t per_c, ui
 // per_c = nchunks: the all-gather form). UNPACK = true: record k of buf, which holds the chunks
 // [cb_u, ce_u) -> particle first + k (equal segments of per records in rank order: record k is
 // particle k).
+// One thread per 16-byte piece of a record (5 of the header, 6 per chunk), ordered so that the
+// WRITES of consecutive threads are consecutive: the pieces of one record when packing, the same
+// piece of consecutive particles when unpacking (a record per thread wrote 16 bytes into 64
+// different lines per instruction).
 template <bool UNPACK>
 __global__ __launch_bounds__(256) void k_shard_records(uint32_t first, uint32_t count, uint32_t n, uint32_t per, uint32_t nchunks,
                                                        uint32_t per_c, uint32_t cb_u, uint32_t ce_u, shard_arrays a, unsigned char *buf)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) {
-        return;
-    }
-    const uint32_t i = first + k;
     uint32_t cb = cb_u, ce = ce_u;
     if constexpr (!UNPACK) {
         shard_block(nchunks, per_c, blockIdx.y, cb, ce);
         buf += static_cast<size_t>(per) * (80u * static_cast<size_t>(blockIdx.y) + 96u * static_cast<size_t>(cb));
     }
-    unsigned char *rec = buf + static_cast<size_t>(k) * shard_record_bytes(ce - cb);
-    uint32_t *r32 = reinterpret_cast<uint32_t *>(rec);
-    double *r64 = reinterpret_cast<double *>(rec);
-    float4 *rf4 = reinterpret_cast<float4 *>(rec + 80) - static_cast<size_t>(cb) * 6u; // indexed by the chunk's own number below
-    if constexpr (!UNPACK) {
-        r32[0] = a.nsub[i];
-        r32[1] = static_cast<uint32_t>(a.status[i]);
-        r32[2] = a.ev_idx[i];
-        r32[3] = 0u;
-        r64[2] = a.ev_time[i];
-        r64[3] = a.nf_last_t[i];
-        for (int j = 0; j < 6; ++j) {
-            r64[4 + j] = a.final_state[static_cast<size_t>(i) * 6u + j];
+    const uint32_t npieces = 5u + 6u * (ce - cb);
+    const size_t rec_bytes = shard_record_bytes(ce - cb);
+    const uint64_t total = static_cast<uint64_t>(count) * npieces;
+    for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        uint32_t k, j;
+        if constexpr (UNPACK) {
+            j = static_cast<uint32_t>(idx / count);
+            k = static_cast<uint32_t>(idx % count);
+        } else {
+            k = static_cast<uint32_t>(idx / npieces);
+            j = static_cast<uint32_t>(idx % npieces);
         }
-        for (uint32_t c = cb; c < ce; ++c) {
+        const uint32_t i = first + k;
+        uint4 *piece = reinterpret_cast<uint4 *>(buf + static_cast<size_t>(k) * rec_bytes + static_cast<size_t>(j) * 16u);
+        if (j >= 5u) {
+            const uint32_t c = cb + (j - 5u) / 6u, t = (j - 5u) % 6u;
             const size_t e = static_cast<size_t>(c) * n + i;
-            rf4[c * 6u] = a.lbs[e];
-            rf4[c * 6u + 1u] = a.ubs[e];
-            for (int j = 0; j < 4; ++j) {
-                rf4[c * 6u + 2u + j] = a.recs ? a.recs[e * 4u + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 *arr = t == 0u ? a.lbs + e : (t == 1u ? a.ubs + e : (a.recs ? a.recs + e * 4u + (t - 2u) : nullptr));
+            if constexpr (!UNPACK) {
+                const float4 v = arr ? *arr : make_float4(0.f, 0.f, 0.f, 0.f);
+                *piece = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+            } else if (arr) {
+                const uint4 v = *piece;
+                *arr = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        } else if (j == 0u) {
+            if constexpr (!UNPACK) {
+                *piece = make_uint4(a.nsub[i], static_cast<uint32_t>(a.status[i]), a.ev_idx[i], 0u);
+            } else {
+                const uint4 v = *piece;
+                a.nsub[i] = v.x;
+                a.status[i] = static_cast<int32_t>(v.y);
+                a.ev_idx[i] = v.z;
+            }
+        } else {
+            // two doubles: {ev_time, nf_last_t} or a pair of the final state
+            double *d0 = j == 1u ? a.ev_time + i : a.final_state + static_cast<size_t>(i) * 6u + 2u * (j - 2u);
+            double *d1 = j == 1u ? a.nf_last_t + i : d0 + 1;
+            double2 *pd = reinterpret_cast<double2 *>(piece);
+            if constexpr (!UNPACK) {
+                *pd = make_double2(*d0, *d1);
+            } else {
+                const double2 v = *pd;
+                *d0 = v.x;
+                *d1 = v.y;
             }
         }
-    } else {
-        a.nsub[i] = r32[0];
-        a.status[i] = static_cast<int32_t>(r32[1]);
-        a.ev_idx[i] = r32[2];
-        a.ev_time[i] = r64[2];
-        a.nf_last_t[i] = r64[3];
-        for (int j = 0; j < 6; ++j) {
-            a.final_state[static_cast<size_t>(i) * 6u + j] = r64[4 + j];
+    }
+}
+
+// Unpacking through LDS: a workgroup copies the records of `pb` consecutive particles into LDS
+// with coalesced 16-byte loads, then writes them out piece by piece with the particle index
+// running fastest, so that both the reads and the writes of consecutive threads are consecutive.
+__global__ __launch_bounds__(256) void k_shard_unpack_staged(uint32_t count, uint32_t n, uint32_t cb, uint32_t ce, uint32_t pb,
+                                                             shard_arrays a, const unsigned char *buf)
+{
+    extern __shared__ uint4 s_rec[];
+    const uint32_t npieces = 5u + 6u * (ce - cb);
+    for (uint32_t k0 = blockIdx.x * pb; k0 < count; k0 += gridDim.x * pb) {
+        const uint32_t m = count - k0 < pb ? count - k0 : pb;
+        const uint4 *src = reinterpret_cast<const uint4 *>(buf + static_cast<size_t>(k0) * npieces * 16u);
+        for (uint32_t t = threadIdx.x; t < m * npieces; t += blockDim.x) {
+            s_rec[t] = src[t];
         }
-        for (uint32_t c = cb; c < ce; ++c) {
-            const size_t e = static_cast<size_t>(c) * n + i;
-            a.lbs[e] = rf4[c * 6u];
-            a.ubs[e] = rf4[c * 6u + 1u];
-            if (a.recs) {
-                for (int j = 0; j < 4; ++j) {
-                    a.recs[e * 4u + j] = rf4[c * 6u + 2u + j];
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < m * npieces; t += blockDim.x) {
+            const uint32_t j = t / m, kk = t % m;
+            const uint32_t i = k0 + kk;
+            const uint4 v = s_rec[kk * npieces + j];
+            if (j >= 5u) {
+                const uint32_t c = cb + (j - 5u) / 6u, tt = (j - 5u) % 6u;
+                const size_t e = static_cast<size_t>(c) * n + i;
+                float4 *arr = tt == 0u ? a.lbs + e : (tt == 1u ? a.ubs + e : (a.recs ? a.recs + e * 4u + (tt - 2u) : nullptr));
+                if (arr) {
+                    *arr = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+            } else if (j == 0u) {
+                a.nsub[i] = v.x;
+                a.status[i] = static_cast<int32_t>(v.y);
+                a.ev_idx[i] = v.z;
+            } else {
+                const double d0 = __hiloint2double(static_cast<int>(v.y), static_cast<int>(v.x));
+                const double d1 = __hiloint2double(static_cast<int>(v.w), static_cast<int>(v.z));
+                if (j == 1u) {
+                    a.ev_time[i] = d0;
+                    a.nf_last_t[i] = d1;
+                } else {
+                    double *d = a.final_state + static_cast<size_t>(i) * 6u + 2u * (j - 2u);
+                    d[0] = d0;
+                    d[1] = d1;
                 }
             }
         }
+        __syncthreads();
+    }
+}
+
+// Packing through LDS, the mirror image: the arrays are read with the particle index running
+// fastest, the records leave LDS as one contiguous run. blockIdx.y = destination segment.
+__global__ __launch_bounds__(256) void k_shard_pack_staged(uint32_t first, uint32_t count, uint32_t n, uint32_t per, uint32_t nchunks,
+                                                           uint32_t per_c, uint32_t pb, shard_arrays a, unsigned char *buf)
+{
+    extern __shared__ uint4 s_rec[];
+    uint32_t cb, ce;
+    shard_block(nchunks, per_c, blockIdx.y, cb, ce);
+    buf += static_cast<size_t>(per) * (80u * static_cast<size_t>(blockIdx.y) + 96u * static_cast<size_t>(cb));
+    const uint32_t npieces = 5u + 6u * (ce - cb);
+    for (uint32_t k0 = blockIdx.x * pb; k0 < count; k0 += gridDim.x * pb) {
+        const uint32_t m = count - k0 < pb ? count - k0 : pb;
+        for (uint32_t t = threadIdx.x; t < m * npieces; t += blockDim.x) {
+            const uint32_t j = t / m, kk = t % m;
+            const uint32_t i = first + k0 + kk;
+            uint4 v;
+            if (j >= 5u) {
+                const uint32_t c = cb + (j - 5u) / 6u, tt = (j - 5u) % 6u;
+                const size_t e = static_cast<size_t>(c) * n + i;
+                const float4 *arr = tt == 0u ? a.lbs + e : (tt == 1u ? a.ubs + e : (a.recs ? a.recs + e * 4u + (tt - 2u) : nullptr));
+                const float4 f = arr ? *arr : make_float4(0.f, 0.f, 0.f, 0.f);
+                v = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+            } else if (j == 0u) {
+                v = make_uint4(a.nsub[i], static_cast<uint32_t>(a.status[i]), a.ev_idx[i], 0u);
+            } else {
+                const double d0 = j == 1u ? a.ev_time[i] : a.final_state[static_cast<size_t>(i) * 6u + 2u * (j - 2u)];
+                const double d1 = j == 1u ? a.nf_last_t[i] : a.final_state[static_cast<size_t>(i) * 6u + 2u * (j - 2u) + 1u];
+                v = make_uint4(static_cast<uint32_t>(__double2loint(d0)), static_cast<uint32_t>(__double2hiint(d0)),
+                               static_cast<uint32_t>(__double2loint(d1)), static_cast<uint32_t>(__double2hiint(d1)));
+            }
+            s_rec[kk * npieces + j] = v;
+        }
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(buf + static_cast<size_t>(k0) * npieces * 16u);
+        for (uint32_t t = threadIdx.x; t < m * npieces; t += blockDim.x) {
+            dst[t] = s_rec[t];
+        }
+        __syncthreads();
     }
 }
 
@@ -1196,6 +1290,20 @@ size_t csc_shard_record_bytes(uint32_t nchunks)
     return shard_record_bytes(nchunks);
 }
 
+// Particles [first, first + count) -> nsegs segments of records (segment y: the chunks of block y).
+static void launch_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t per, uint32_t nchunks, uint32_t nsegs,
+                              const shard_arrays &a, void *d_records);
+// Records of particles [0, n) with the chunks [cb, ce) -> the arrays.
+static void launch_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, uint32_t cb, uint32_t ce, const shard_arrays &a,
+                                const void *d_records);
+
+// Workgroups for `count` records of 5 + 6 * chunks pieces (the kernel strides over the rest).
+static unsigned shard_grid(uint32_t count, uint32_t chunks)
+{
+    const uint64_t pieces = static_cast<uint64_t>(count) * (5u + 6u * static_cast<uint64_t>(chunks));
+    return static_cast<unsigned>(std::min<uint64_t>(std::max<uint64_t>(cdiv(pieces, static_cast<uint64_t>(256)), 1u), 65536u));
+}
+
 int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t nchunks, const uint32_t *d_nsub,
                    const int32_t *d_status, const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,
                    const double *d_final_state, const float *d_lbs, const float *d_ubs, const float *d_recs, void *d_records)
@@ -1210,8 +1318,7 @@ int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uin
                    const_cast<double *>(d_ev_time), const_cast<double *>(d_nf_last_t), const_cast<double *>(d_final_state),
                    reinterpret_cast<float4 *>(const_cast<float *>(d_lbs)), reinterpret_cast<float4 *>(const_cast<float *>(d_ubs)),
                    reinterpret_cast<float4 *>(const_cast<float *>(d_recs))};
-    KT("k_shard_pack", hipLaunchKernelGGL((k_shard_records<false>), dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, first, count, n,
-                                           count, nchunks, nchunks, 0u, 0u, a, static_cast<unsigned char *>(d_records)));
+    launch_shard_pack(ctx, n, first, count, count, nchunks, 1u, a, d_records);
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -1246,9 +1353,7 @@ int csc_shard_pack_blocks(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t cou
                    const_cast<double *>(d_ev_time), const_cast<double *>(d_nf_last_t), const_cast<double *>(d_final_state),
                    reinterpret_cast<float4 *>(const_cast<float *>(d_lbs)), reinterpret_cast<float4 *>(const_cast<float *>(d_ubs)),
                    reinterpret_cast<float4 *>(const_cast<float *>(d_recs))};
-    KT("k_shard_pack", hipLaunchKernelGGL((k_shard_records<false>), dim3(cdiv(count, 256), nranks), dim3(256), 0, ctx->stream, first,
-                                           count, n, per_rank, nchunks, cdiv(nchunks, nranks), 0u, 0u, a,
-                                           static_cast<unsigned char *>(d_records)));
+    launch_shard_pack(ctx, n, first, count, per_rank, nchunks, nranks, a, d_records);
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -1265,9 +1370,7 @@ int csc_shard_unpack_block(csc_ctx *ctx, uint32_t n, uint32_t nchunks, uint32_t 
     }
     shard_arrays a{d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, reinterpret_cast<float4 *>(d_lbs),
                    reinterpret_cast<float4 *>(d_ubs), reinterpret_cast<float4 *>(d_recs)};
-    KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, 0u, n, n, n, nchunks,
-                                             nchunks, chunk_first, chunk_first + chunk_count, a,
-                                             static_cast<unsigned char *>(const_cast<void *>(d_records))));
+    launch_shard_unpack(ctx, n, nchunks, chunk_first, chunk_first + chunk_count, a, d_records);
     CSC_LAUNCH_CHECK();
     return CSC_OK;
 }
@@ -1281,10 +1384,40 @@ int csc_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const void *d_r
     }
     shard_arrays a{d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, reinterpret_cast<float4 *>(d_lbs),
                    reinterpret_cast<float4 *>(d_ubs), reinterpret_cast<float4 *>(d_recs)};
-    KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, 0u, n, n, n, nchunks,
-                                             nchunks, 0u, nchunks, a, static_cast<unsigned char *>(const_cast<void *>(d_records))));
+    launch_shard_unpack(ctx, n, nchunks, 0u, nchunks, a, d_records);
     CSC_LAUNCH_CHECK();
     return CSC_OK;
+}
+
+static void launch_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t per, uint32_t nchunks, uint32_t nsegs,
+                              const shard_arrays &a, void *d_records)
+{
+    const uint32_t per_c = cdiv(nchunks, nsegs);
+    const size_t rec = shard_record_bytes(per_c);
+    const uint32_t pb = static_cast<uint32_t>(std::min<size_t>(64u, 49152u / rec));
+    if (pb >= 8u) {
+        const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(cdiv(count, pb), 8192u));
+        KT("k_shard_pack", hipLaunchKernelGGL(k_shard_pack_staged, dim3(grid, nsegs), dim3(256), pb * rec, ctx->stream, first, count, n, per,
+                                               nchunks, per_c, pb, a, static_cast<unsigned char *>(d_records)));
+    } else {
+        KT("k_shard_pack", hipLaunchKernelGGL((k_shard_records<false>), dim3(shard_grid(count, per_c), nsegs), dim3(256), 0, ctx->stream, first,
+                                               count, n, per, nchunks, per_c, 0u, 0u, a, static_cast<unsigned char *>(d_records)));
+    }
+}
+
+static void launch_shard_unpack(csc_ctx *ctx, uint32_t n, uint32_t nchunks, uint32_t cb, uint32_t ce, const shard_arrays &a,
+                                const void *d_records)
+{
+    const size_t rec = shard_record_bytes(ce - cb);
+    const uint32_t pb = static_cast<uint32_t>(std::min<size_t>(64u, 49152u / rec));
+    if (pb >= 8u) {
+        const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(cdiv(n, pb), 8192u));
+        KT("k_shard_unpack", hipLaunchKernelGGL(k_shard_unpack_staged, dim3(grid), dim3(256), pb * rec, ctx->stream, n, n, cb, ce, pb, a,
+                                                 static_cast<const unsigned char *>(d_records)));
+    } else {
+        KT("k_shard_unpack", hipLaunchKernelGGL((k_shard_records<true>), dim3(shard_grid(n, ce - cb)), dim3(256), 0, ctx->stream, 0u, n, n, n,
+                                                 nchunks, nchunks, cb, ce, a, static_cast<unsigned char *>(const_cast<void *>(d_records))));
+    }
 }
 
 int csc_propagate_range(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
