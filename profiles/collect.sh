@@ -10,7 +10,8 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+# (without the default-mode and C = 1 legs and the CPU check, so that every launch in the table belongs to the timed configuration)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 bench.py --no-cpu-baseline --no-host-sync-leg > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo "stats pass done"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-sync-leg > $OUT/fetch.json 2> $OUT/fetch.log
 echo "fetch pass done"
