@@ -1763,9 +1763,16 @@ static int bvh_build_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint
     } else {
         KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit_fast, gn, blk, 0, ctx->stream, b));
     }
-    // Bottom-up refit in one launch (arrival counters start from zero).
+    // Bottom-up refit (arrival counters start from zero): the subtrees inside a workgroup's leaves
+    // first (Karras numbering only), then one launch across workgroups. CASCADE_BVH_REFIT=global:
+    // the second kernel alone, from the leaves (measurements).
     CSC_HIP(hipMemsetAsync(b.visit, 0, cnn * sizeof(uint32_t), ctx->stream));
-    KT("k_bvh_refit", hipLaunchKernelGGL(csc::k_bvh_refit, gn, blk, 0, ctx->stream, b));
+    const char *er = std::getenv("CASCADE_BVH_REFIT");
+    const bool local_first = !canonical && !(er && std::string(er) == "global");
+    if (local_first) {
+        KT("k_bvh_refit_local", hipLaunchKernelGGL(csc::k_bvh_refit_local, gp, blk, 0, ctx->stream, b));
+    }
+    KT("k_bvh_refit", hipLaunchKernelGGL(csc::k_bvh_refit, gn, blk, 0, ctx->stream, b, local_first ? 1 : 0));
     CSC_LAUNCH_CHECK();
     ctx->bvh = b;
     ctx->bvh_packed = false;

@@ -373,15 +373,76 @@ CSC_DEV float ld_agent(const float *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-CSC_GLOBAL __launch_bounds__(256) void k_bvh_refit(bvh_bufs b)
+// First the subtrees that lie inside one workgroup's 256 consecutive leaves, with LDS counters and
+// LDS hand-off (k_bvh_emit_fast numbering only: a leaf finds its node from the Karras arrays, and
+// a node's Karras id is (left child - 1) / 2): a thread climbs with its box in registers; at a
+// parent whose range of leaves lies within the workgroup's it leaves its box in the parent's slot
+// for its side and bumps the parent's counter (workgroup-scope acq_rel: plain s_waitcnt on
+// gfx950); the first arrival stops, the second one reads the sibling's slot, forms the union,
+// stores it as the parent's box and goes on. A thread that reaches a parent outside the workgroup
+// flags its node (ndepth, free in this numbering) and stops: k_bvh_refit below continues from the
+// flagged nodes across workgroups, after the kernel boundary has made every box visible. At 1M
+// objects 1 node in 40 is left to the device-scope atomics. min / max are exact and
+// order-independent: same boxes bit for bit.
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_refit_local(bvh_bufs b)
+{
+    __shared__ float4 s_lb[512], s_ub[512];
+    __shared__ std::uint32_t s_cnt[256];
+    const std::uint32_t c = blockIdx.y;
+    const std::uint32_t nn = b.n_nodes[c], M = (nn + 1u) / 2u;
+    const std::uint32_t R0 = blockIdx.x * 256u;
+    if (R0 >= M || M == 1u) {
+        return; // (the whole workgroup; a root that is a leaf has its box from the emit kernel)
+    }
+    s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const std::uint32_t r = R0 + threadIdx.x;
+    if (r >= M) {
+        return; // (no barrier below)
+    }
+    const std::uint32_t R1 = R0 + 256u < M ? R0 + 256u : M;
+    const std::size_t no = static_cast<std::size_t>(c) * b.nn_max, po = static_cast<std::size_t>(c) * b.n;
+    const std::int32_t kid_leaf = static_cast<std::int32_t>((M - 1u) + r);
+    const std::int32_t kp = b.k_parent[no + kid_leaf];
+    std::uint32_t cur = 2u * static_cast<std::uint32_t>(kp) + 1u + (b.k_right[po + kp] == kid_leaf ? 1u : 0u);
+    float4 lb = b.nlb[no + cur], ub = b.nub[no + cur];
+    while (true) {
+        const std::int32_t par = b.npar[no + cur];
+        if (par < 0) {
+            return; // cur is the root and its box is stored
+        }
+        const std::uint32_t left = static_cast<std::uint32_t>(b.nleft[no + par]);
+        const std::uint32_t kid = (left - 1u) >> 1;
+        if (b.k_first[po + kid] < R0 || b.k_last[po + kid] >= R1) {
+            b.ndepth[no + cur] = 1u; // continued by k_bvh_refit
+            return;
+        }
+        const std::uint32_t slot = kid - R0, side = cur == left ? 0u : 1u;
+        s_lb[2u * slot + side] = lb;
+        s_ub[2u * slot + side] = ub;
+        if (__hip_atomic_fetch_add(&s_cnt[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+            return;
+        }
+        // (left, right) operand order as in k_bvh_refit: the same bits even for zeros of opposite sign
+        const float4 l0 = s_lb[2u * slot], l1 = s_lb[2u * slot + 1u], u0 = s_ub[2u * slot], u1 = s_ub[2u * slot + 1u];
+        lb = make_float4(fminf_std(l0.x, l1.x), fminf_std(l0.y, l1.y), fminf_std(l0.z, l1.z), fminf_std(l0.w, l1.w));
+        ub = make_float4(fmaxf_std(u0.x, u1.x), fmaxf_std(u0.y, u1.y), fmaxf_std(u0.z, u1.z), fmaxf_std(u0.w, u1.w));
+        cur = static_cast<std::uint32_t>(par);
+        b.nlb[no + cur] = lb;
+        b.nub[no + cur] = ub;
+    }
+}
+
+// flagged != 0: the climbs start at the nodes k_bvh_refit_local flagged (ndepth) instead of at the leaves.
+CSC_GLOBAL __launch_bounds__(256) void k_bvh_refit(bvh_bufs b, int flagged)
 {
     const std::uint32_t c = blockIdx.y, p0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (p0 >= b.n_nodes[c]) {
         return;
     }
     const std::size_t no = static_cast<std::size_t>(c) * b.nn_max;
-    if (b.nleft[no + p0] >= 0) {
-        return; // climbs start at the leaves
+    if (flagged ? b.ndepth[no + p0] == 0u : b.nleft[no + p0] >= 0) {
+        return; // climbs start at the leaves (at the flagged roots of the workgroup-local subtrees)
     }
     std::int32_t cur = b.npar[no + p0];
     while (cur >= 0) {

@@ -126,7 +126,8 @@ def test_refit_handoff_isa():
         assert dev, os.listdir(tmp)
         asm = subprocess.check_output([objdump, "-d", "--no-show-raw-insn", os.path.join(tmp, dev[0])], text=True)
     lines = asm.splitlines()
-    start = next(i for i, l in enumerate(lines) if "k_bvh_refit" in l and l.rstrip().endswith(">:"))
+    # (the cross-workgroup kernel; k_bvh_refit_local, which runs before it, hands off through LDS)
+    start = next(i for i, l in enumerate(lines) if "11k_bvh_refitE" in l and l.rstrip().endswith(">:"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = [l.split("//")[0].strip() for l in lines[start:end]]
     mem = [l for l in body if l.startswith(("global_", "flat_", "buffer_", "s_waitcnt vmcnt"))]

@@ -127,6 +127,20 @@ def test_pipeline_invariants_1m(orc, pop):
         expect = np.flatnonzero(ov)
         mine = np.concatenate([got[got[:, 0] == p, 1], got[got[:, 1] == p, 0]])
         assert np.array_equal(np.sort(mine), expect), "pairs of a sampled object = brute force"
+    # That was the tree in the reference's node order (the export rebuilt it that way). The tree as
+    # csc_bvh_build numbers it (Karras ids, workgroup-local refit first): same pairs, and the same
+    # traversal work, which depends on every internal box.
+    work = (L.csc_broad_phase_node_pairs(h), L.csc_broad_phase_tiles(h))
+    chk(L.csc_bvh_build(h, n, 1, d_sc.ptr, d_slb.ptr, d_sub.ptr))
+    npairs2 = C.c_uint64()
+    chk(L.csc_broad_phase(h, n, 1, d_slb.ptr, d_sub.ptr, d_vidx.ptr, d_act.ptr, C.byref(npairs2)))
+    assert npairs2.value == npairs.value
+    assert (L.csc_broad_phase_node_pairs(h), L.csc_broad_phase_tiles(h)) == work
+    got2 = np.empty((npairs2.value, 2), dtype=np.uint32)
+    chk(L.csc_broad_phase_get(h, 0, got2.ctypes.data_as(C.c_void_p), len(got2), C.byref(cnt)))
+    key2 = got2[:, 0].astype(np.uint64) << np.uint64(32) | got2[:, 1].astype(np.uint64)
+    key2.sort()
+    assert np.array_equal(key, key2)
     ctx.close()
 
 

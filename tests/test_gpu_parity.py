@@ -100,20 +100,28 @@ def test_tree_order_changes_nothing(orc, monkeypatch):
 
     from _stage_parity import check_aabb_to_pairs
 
-    st = _pop(5003, seed=11, same_code=True)
-    s, _ = _oracle_step(orc, st, 2)
-    counts = []
-    for canon in ("1", None):
-        if canon is None:
-            monkeypatch.delenv("CASCADE_BVH_CANONICAL", raising=False)
-        else:
-            monkeypatch.setenv("CASCADE_BVH_CANONICAL", canon)
-        c2 = _capi.Context(0)
-        try:
-            counts.append(check_aabb_to_pairs(orc, c2, s, len(st)))
-        finally:
-            c2.close()
-    assert counts[0] == counts[1] == sum(len(s.bp_pairs(c)) for c in range(2))
+    for n in (5003, 40001):
+        st = _pop(n, seed=11, same_code=True)
+        s, _ = _oracle_step(orc, st, 2)
+        counts, work = [], []
+        # the reference's order; Karras numbering with the cross-workgroup refit alone; with the
+        # workgroup-local refit in front of it (the default)
+        for canon, refit in (("1", None), (None, "global"), (None, None)):
+            for var, val in (("CASCADE_BVH_CANONICAL", canon), ("CASCADE_BVH_REFIT", refit)):
+                if val is None:
+                    monkeypatch.delenv(var, raising=False)
+                else:
+                    monkeypatch.setenv(var, val)
+            c2 = _capi.Context(0)
+            try:
+                counts.append(check_aabb_to_pairs(orc, c2, s, len(st)))
+                # The traversal's work depends on every internal box: equal counts = equal boxes
+                # as far as any pair of nodes can tell.
+                work.append((int(c2.L.csc_broad_phase_node_pairs(c2.h)), int(c2.L.csc_broad_phase_tiles(c2.h))))
+            finally:
+                c2.close()
+        assert counts[0] == counts[1] == counts[2] == sum(len(s.bp_pairs(c)) for c in range(2))
+        assert work[0] == work[1] == work[2] and work[0][0] > 0, work
 
 
 def test_tiles_change_nothing(orc, ctx, monkeypatch):
