@@ -1975,13 +1975,18 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         ctx->dt_level_items.assign(static_cast<size_t>(level) + 1u, 0);
         for (int l = 0; l <= level; ++l) {
             uint64_t at_level = 0;
+            uint32_t max_shard = 0;
             for (int s = 0; s < DT_SHARDS; ++s) {
                 const uint32_t v = hc[ctr_per_level * l + static_cast<size_t>(s) * DT_CTR_STRIDE];
                 max_fr = std::max(max_fr, v);
+                max_shard = std::max(max_shard, v);
                 at_level += v;
             }
             items += at_level;
-            ctx->dt_level_items[l] = at_level;
+            // (for the grid of the next traversal: every shard gets the workgroups its fullest one
+            // needs -- the upper levels sit in a few shards, and a workgroup that walks 16 tiles of
+            // its shard one after the other costs 16 memory round trips)
+            ctx->dt_level_items[l] = static_cast<uint64_t>(max_shard) * DT_SHARDS;
             if (at_level) {
                 used_levels = l + 1;
             }

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lvl -o t -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-host-sync-leg > gpurun_out/lvl/bench.json 2> gpurun_out/lvl/err.log
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lvl -o t -- python3 bench.py --n-par-ct 1 --steps 2 --warmup 2 --no-cpu-baseline --no-host-sync-leg > gpurun_out/lvl/bench.json 2> gpurun_out/lvl/err.log
 python3 - <<'PY'
 import csv,glob
 f=glob.glob('gpurun_out/lvl/**/t_kernel_trace.csv',recursive=True)[0]
