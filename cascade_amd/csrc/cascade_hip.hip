@@ -74,6 +74,9 @@ struct csc_ctx {
     std::string err;
     std::map<std::string, dbuf> bufs;
     int *d_flags = nullptr; // [0] morton non-finite box, [1] dense: no substeps, [2] broad-phase stack overflow, [3] store pass != pass 1
+    // The flags were read clean (by the dual broad phase, together with its counters) and no kernel
+    // that can raise one has been launched since: csc_check_flags need not synchronise.
+    bool flags_fresh = false;
     // BVH state of the last csc_bvh_build
     csc::bvh_bufs bvh{};
     uint32_t bvh_n = 0, bvh_chunks = 0;
@@ -1198,6 +1201,9 @@ int csc_profile_get(csc_ctx *ctx, char *buf, size_t cap)
 
 int csc_check_flags(csc_ctx *ctx)
 {
+    if (ctx->flags_fresh) {
+        return CSC_OK;
+    }
     int h[4] = {0, 0, 0, 0};
     CSC_HIP(hipMemcpyAsync(h, ctx->d_flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     CSC_HIP(hipStreamSynchronize(ctx->stream));
@@ -1465,6 +1471,7 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
     p.order = d_order;
     p.nsub_in = d_nsub;
     p.store_err = ctx->d_flags + 3;
+    ctx->flags_fresh = false;
     p.row_base = d_base;
     p.tc_row = d_tc_row;
     p.tcs_xyz = d_tcs_xyz;
@@ -1600,6 +1607,7 @@ int csc_global_aabb_noalloc(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
 int csc_morton_encode(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_lbs, const float *d_ubs,
                       const float *d_glb, const float *d_gub, uint64_t *d_codes)
 {
+    ctx->flags_fresh = false;
     KT("k_morton", hipLaunchKernelGGL(csc::k_morton, dim3(cdiv(n, 256), nchunks), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const float4 *>(d_lbs), reinterpret_cast<const float4 *>(d_ubs), n,
                        reinterpret_cast<const float4 *>(d_glb), reinterpret_cast<const float4 *>(d_gub), d_codes,
@@ -1911,11 +1919,31 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         q.sleaf = d_sleaf;
         int level = 0;
         bool done = false;
-        ctx->kt_begin("k_bp_dual");
+        // Tiles are handed to k_bp_tiles as soon as the levels the last traversal needed (+ 1) have
+        // been launched, without waiting to see that the frontier is empty: ONE read-back of all
+        // counters (and of the sticky flags) per traversal. If the tree got deeper, the remaining
+        // levels run and a second tile launch takes the tiles added since.
+        std::vector<uint32_t> tiles_done(DT_SHARDS, 0u);
+        bool tiles_seen = false;
+        int flags_h[4] = {0, 0, 0, 0};
+        auto launch_tiles = [&]() {
+            for (int s = 0; s < DT_SHARDS; ++s) {
+                q.tile_begin[s] = tiles_done[s];
+            }
+            // Workgroups stride over the tile batches of their shard: 8 per CU fill the chip.
+            const unsigned tg = static_cast<uint64_t>(n) * nchunks >= 200000u ? 2048u : 256u;
+            if (tile_max <= 8u) {
+                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            } else {
+                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<16>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            }
+        };
+        bool tiles_launched = false;
         while (!done && level < DT_MAX_LEVELS) {
             // A batch of levels, then a look at the size of the frontier they left.
             // (first batch: as many levels as the last traversal needed, plus one)
             const int batch_end = std::min(DT_MAX_LEVELS, level + (level == 0 ? (ctx->dt_levels ? ctx->dt_levels + 1 : 32) : 8));
+            ctx->kt_begin("k_bp_dual");
             for (; level < batch_end; ++level) {
                 q.level = static_cast<uint32_t>(level);
                 q.in = (level % 2 == 0) ? d_fa : d_fb;
@@ -1933,34 +1961,50 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
                 }
                 hipLaunchKernelGGL(k_bp_dual, dim3(g), dim3(DT_BLOCK), 0, ctx->stream, q);
             }
+            ctx->kt_end("k_bp_dual");
             CSC_LAUNCH_CHECK();
-            CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * level, d_cnt + ctr_per_level * level, ctr_per_level * sizeof(uint32_t),
+            if (tile_max != 0u && !tiles_launched) {
+                launch_tiles();
+                CSC_LAUNCH_CHECK();
+                tiles_launched = true;
+            }
+            // Everything the host wants to know, in one go.
+            CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, ctr_per_level * (level + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 2 * ctr_per_level * sizeof(uint32_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
+            CSC_HIP(hipMemcpyAsync(flags_h, ctx->d_flags, sizeof(flags_h), hipMemcpyDeviceToHost, ctx->stream));
             CSC_HIP(hipStreamSynchronize(ctx->stream));
             done = true;
             for (int s = 0; s < DT_SHARDS; ++s) {
                 done = done && hc[ctr_per_level * level + static_cast<size_t>(s) * DT_CTR_STRIDE] == 0u;
             }
+            if (tile_max != 0u && !tiles_seen) {
+                // (what the first tile launch saw: the tile counts at that point)
+                for (int s = 0; s < DT_SHARDS; ++s) {
+                    tiles_done[s] = std::min(hc[ctr_per_level * (DT_MAX_LEVELS + 2) + static_cast<size_t>(s) * DT_CTR_STRIDE], tile_cap);
+                }
+                tiles_seen = true;
+            }
         }
-        ctx->kt_end("k_bp_dual");
         if (!done) {
             ctx->err = "broad phase: the dual traversal did not terminate";
             return CSC_ERR_OVERFLOW;
         }
         if (tile_max != 0u) {
-            // Workgroups stride over the tile batches of their shard: 8 per CU fill the chip.
-            const unsigned tg = static_cast<uint64_t>(n) * nchunks >= 200000u ? 2048u : 256u;
-            if (tile_max <= 8u) {
-                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
-            } else {
-                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<16>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            // Tiles that arrived after the first tile launch (the tree got deeper than last time)?
+            bool more = false;
+            for (int s = 0; s < DT_SHARDS; ++s) {
+                more = more || std::min(hc[ctr_per_level * (DT_MAX_LEVELS + 2) + static_cast<size_t>(s) * DT_CTR_STRIDE], tile_cap) > tiles_done[s];
             }
-            CSC_LAUNCH_CHECK();
+            if (more) {
+                launch_tiles();
+                CSC_LAUNCH_CHECK();
+                CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 2 * ctr_per_level * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+                CSC_HIP(hipStreamSynchronize(ctx->stream));
+            }
         }
-        CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, ctr_per_level * (level + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 2 * ctr_per_level * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, ctx->stream));
-        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->flags_fresh = flags_h[0] == 0 && flags_h[1] == 0 && flags_h[2] == 0 && flags_h[3] == 0;
         uint32_t max_fr = 0, max_pr = 0, max_tl = 0;
         uint64_t ntiles = 0;
         for (int s = 0; s < DT_SHARDS; ++s) {
@@ -2086,6 +2130,7 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     q.active = d_active;
     q.counter = ctx->d_bp_counter;
     q.err_flag = ctx->d_flags + 2;
+    ctx->flags_fresh = false;
     // Query groups of this process (all of them when there is one process).
     const uint32_t ngroups_all = cdiv(n, 64);
     const uint32_t ngroups = cdiv(ngroups_all, csc::BP_SHARD_RUN * ctx->shard_n) * csc::BP_SHARD_RUN;
@@ -2190,6 +2235,7 @@ int csc_broad_phase_stats(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const floa
     q.active = d_active;
     q.counter = ctx->d_bp_counter;
     q.err_flag = ctx->d_flags + 2;
+    ctx->flags_fresh = false;
     CSC_HIP(hipMemsetAsync(ctx->d_bp_counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(csc::k_broad_phase_stats, dim3(cdiv(n, csc::BP_BLOCK), nchunks), dim3(csc::BP_BLOCK), 0, ctx->stream, q);
     CSC_LAUNCH_CHECK();
@@ -2744,6 +2790,7 @@ int csc_dense_propagate(csc_ctx *ctx, uint32_t n, uint32_t order, double t, cons
                         const uint32_t *d_nsub, const double *d_tcs_xyz, const double *d_tcs_vr, const double *d_tcoords,
                         double *d_out)
 {
+    ctx->flags_fresh = false;
     if (order != 20u) {
         const csc::order_api *oapi = csc_order_api(static_cast<int>(order));
         if (oapi == nullptr) {

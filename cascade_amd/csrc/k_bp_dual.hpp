@@ -69,6 +69,7 @@ struct dual_params {
     unsigned long long *tiles;    // [DT_SHARDS][tile_cap]
     std::uint32_t *tile_cnt;      // [DT_SHARDS * DT_CTR_STRIDE]
     std::uint32_t tile_cap;
+    std::uint32_t tile_begin[DT_SHARDS]; // k_bp_tiles starts here in every shard's list (a second launch: the tiles added since)
     const std::uint32_t *sinfo;   // [C][n] orig | act << 24 | multi-leaf member << 26 (k_bvh_pack)
     const std::uint32_t *sleaf;   // [C][n] leaf of a multi-leaf member
 };
@@ -525,8 +526,10 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
     const std::uint32_t ybase = gbase + lane / TL, yslot = ybase + xi; // (padded staging slots)
     const std::uint32_t shard = blockIdx.x % DT_SHARDS;
     const std::uint32_t cnt_raw = q.tile_cnt[shard * DT_CTR_STRIDE];
-    const std::uint32_t cnt = cnt_raw < q.tile_cap ? cnt_raw : q.tile_cap;
-    const unsigned long long *tiles = q.tiles + static_cast<std::size_t>(shard) * q.tile_cap;
+    const std::uint32_t cnt_all = cnt_raw < q.tile_cap ? cnt_raw : q.tile_cap;
+    const std::uint32_t tbegin = q.tile_begin[shard] < cnt_all ? q.tile_begin[shard] : cnt_all;
+    const std::uint32_t cnt = cnt_all - tbegin; // tiles [tbegin, cnt_all) of the shard's list
+    const unsigned long long *tiles = q.tiles + static_cast<std::size_t>(shard) * q.tile_cap + tbegin;
     unsigned long long *pout = q.pairs + static_cast<std::size_t>(shard) * q.pair_cap;
     std::uint32_t *pair_cnt = q.pair_cnt + shard * DT_CTR_STRIDE;
     unsigned long long *buf = s_buf[wave];
