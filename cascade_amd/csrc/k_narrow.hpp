@@ -563,7 +563,9 @@ CSC_DEV bool np_prefilter_core(const float (&dx)[5], const float (&dy)[5], const
         const float ex = dx[sidx + 1] - dx[sidx], ey = dy[sidx + 1] - dy[sidx], ez = dz[sidx + 1] - dz[sidx];
         const float ee = ex * ex + ey * ey + ez * ez;
         const float de = dx[sidx] * ex + dy[sidx] * ey + dz[sidx] * ez;
-        float u = ee > 0.f ? -de / ee : 0.f;
+        // (v_rcp_f32, 1 ulp, instead of the 10-instruction IEEE division: at the minimiser the
+        // distance is stationary in u, so an error of 3e-7 in u changes m2 by ~1e-13 |e|^2)
+        float u = ee > 0.f ? -de * __builtin_amdgcn_rcpf(ee) : 0.f;
         u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
         const float mx = dx[sidx] + u * ex, my = dy[sidx] + u * ey, mz = dz[sidx] + u * ez;
         const float m2 = mx * mx + my * my + mz * mz;
