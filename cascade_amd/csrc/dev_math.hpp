@@ -230,6 +230,26 @@ CSC_DEV ivl iv_poly_eval(const double *a, ivl h)
     return acc;
 }
 
+// The same enclosure for 0 <= h.lo <= h.hi (the sub-interval of a Taylor step that a chunk covers).
+// There the extreme products follow from the signs of acc's bounds, and because rounding is
+// monotonic the product selected IS the minimum (maximum) of iv_mul's four rounded products: the
+// bounds are bit-identical, at 2 multiplications and 2 selects per step instead of 4 and 12. (A zero
+// product may differ in sign; the addition of the next coefficient removes it, and a series of
+// zeros ends in nextafterf, which does not see the sign. Non-finite coefficients can differ; the
+// caller rejects a non-finite box either way.)
+template <int P>
+CSC_DEV ivl iv_poly_eval_nonneg(const double *a, ivl h)
+{
+    ivl acc{a[P], a[P]};
+#pragma unroll
+    for (int i = 1; i <= P; ++i) {
+        const double ml = acc.lo < 0. ? h.hi : h.lo;
+        const double mh = acc.hi < 0. ? h.lo : h.hi;
+        acc = ivl{a[P - i] + acc.lo * ml, a[P - i] + acc.hi * mh};
+    }
+    return acc;
+}
+
 // fex_check (heyoka llvm_add_fex_check, EXTERNAL; src/sim_jit.cpp:234).
 template <int P>
 CSC_DEV bool fex_excluded(const double *cf, double h)

@@ -175,17 +175,25 @@ __global__ __launch_bounds__(256) void k_gather_aabb(const float4 *lbs, const fl
 {
     const std::uint32_t chunk = blockIdx.y;
     const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
     const std::size_t off = static_cast<std::size_t>(chunk) * n;
-    const std::uint32_t s = vidx[off + i];
-    srt_lbs[off + i] = lbs[off + s];
-    srt_ubs[off + i] = ubs[off + s];
+    const std::uint32_t s = i < n ? vidx[off + i] : 0u;
+    if (i < n) {
+        srt_lbs[off + i] = lbs[off + s];
+        srt_ubs[off + i] = ubs[off + s];
+    }
     if (recs != nullptr) {
+        // Four lanes per record: one 64-byte request per gathered record, and every store of the
+        // wave covers 1024 contiguous bytes (one lane per record would write 16 bytes of 64 lines).
+        const std::uint32_t lane = threadIdx.x & 63u, piece = lane & 3u;
+        const std::uint32_t wave_base = i - lane;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            srt_recs[(off + i) * 4u + k] = recs[(off + s) * 4u + k];
+        for (std::uint32_t q = 0; q < 4; ++q) {
+            const std::uint32_t src_lane = 16u * q + (lane >> 2);
+            const std::uint32_t sq = static_cast<std::uint32_t>(__shfl(static_cast<int>(s), static_cast<int>(src_lane)));
+            const std::uint32_t obj = wave_base + src_lane;
+            if (obj < n) {
+                srt_recs[(off + obj) * 4u + piece] = recs[(off + sq) * 4u + piece];
+            }
         }
     }
 }

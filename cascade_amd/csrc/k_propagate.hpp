@@ -967,7 +967,8 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                     const double *arrs[4] = {t.x, t.y, t.z, t.r};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        ivl v = iv_poly_eval<P>(arrs[q], hint);
+                        // (0 <= hint.lo < hint.hi: ev_lb >= tc_prev, and cb < tc, ce > tc_prev, cb < ce, tc_prev < tc)
+                        ivl v = iv_poly_eval_nonneg<P>(arrs[q], hint);
                         v.lo -= infl;
                         v.hi += infl;
                         const float fl = nextafterf(static_cast<float>(v.lo), -finf);
