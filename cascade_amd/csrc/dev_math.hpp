@@ -243,6 +243,8 @@ CSC_DEV ivl iv_poly_eval_nonneg(const double *a, ivl h)
     ivl acc{a[P], a[P]};
 #pragma unroll
     for (int i = 1; i <= P; ++i) {
+        // (selecting the factor, 1 compare + 2 v_cndmask, measured faster than v_min_f64 / v_max_f64
+        // of both products: 3.13 against 3.30 ms for k_propagate_rows at 8 chunks)
         const double ml = acc.lo < 0. ? h.hi : h.lo;
         const double mh = acc.hi < 0. ? h.lo : h.hi;
         acc = ivl{a[P - i] + acc.lo * ml, a[P - i] + acc.hi * mh};
