@@ -561,14 +561,15 @@ CSC_DEV bool np_prefilter_core(const float (&dx)[5], const float (&dy)[5], const
     for (int sidx = 0; sidx < 4; ++sidx) {
         // min over u in [0, 1] of |d_s + u (d_{s+1} - d_s)|^2
         const float ex = dx[sidx + 1] - dx[sidx], ey = dy[sidx + 1] - dy[sidx], ez = dz[sidx + 1] - dz[sidx];
-        const float ee = ex * ex + ey * ey + ez * ez;
-        const float de = dx[sidx] * ex + dy[sidx] * ey + dz[sidx] * ez;
+        // (explicit fused multiply-adds: the library is built with -ffp-contract=off for the FP64 stages)
+        const float ee = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+        const float de = fmaf(dx[sidx], ex, fmaf(dy[sidx], ey, dz[sidx] * ez));
         // (v_rcp_f32, 1 ulp, instead of the 10-instruction IEEE division: at the minimiser the
         // distance is stationary in u, so an error of 3e-7 in u changes m2 by ~1e-13 |e|^2)
         float u = ee > 0.f ? -de * __builtin_amdgcn_rcpf(ee) : 0.f;
         u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
-        const float mx = dx[sidx] + u * ex, my = dy[sidx] + u * ey, mz = dz[sidx] + u * ez;
-        const float m2 = mx * mx + my * my + mz * mz;
+        const float mx = fmaf(u, ex, dx[sidx]), my = fmaf(u, ey, dy[sidx]), mz = fmaf(u, ez, dz[sidx]);
+        const float m2 = fmaf(mx, mx, fmaf(my, my, mz * mz));
         // Any u in [0, 1] gives an upper bound of the true minimum only if it IS the minimiser;
         // rounding of u moves the point along the segment by ~1e-7 |e|, which the margin in dev
         // and the factor on thr absorb. NaNs compare false: the pair is kept.
@@ -620,8 +621,11 @@ __global__ __launch_bounds__(64) void k_np_prefilter(const np_params q)
 // candidate on the list's counter serialises at ~10 ns each (same address), which WAS this
 // kernel's time: 0.32 ms for 27 k candidates, 4.3 ms for 424 k (1M objects, 1 and 8 chunks),
 // whatever the record size (a 32-byte quantised copy of the records, tested first, changed
-// nothing and was removed again) or the number of pairs in flight per lane. Since then: 0.26 and
-// 2.5 ms, the rate at which L1 looks up the 8 x 64 cache lines of a wave's record loads.
+// nothing and was removed again) or the number of pairs in flight per lane. Since then: 0.22 and
+// 2.3 ms = 10 ps per pair whatever the population (62 k to 4M objects: it is not a cache effect),
+// 57 % of it VALU issue (204 instructions per 64 pairs). Loading each record with four lanes and
+// handing it over through LDS (16 instead of 64 cache lines per load instruction) was tried and
+// changed nothing either (0.24 / 2.3 ms): the L1 lookup rate is not the bound.
 constexpr unsigned NP_FLAT_CBUF = 2 * NP_FLAT_TILE; // flushed before a tile when more than half full
 
 template <bool FILTER>
