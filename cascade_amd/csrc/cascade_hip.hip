@@ -1859,7 +1859,8 @@ int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
 static_assert(csc::NP_FLAT_SHARDS == csc::DT_SHARDS, "flat pair lists");
 static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                             const uint32_t *d_vidx, const uint8_t *d_active, const csc::tnode *d_tn, const uint8_t *d_sact,
-                            const uint32_t *d_sinfo, const uint32_t *d_sleaf, uint32_t tile_max, uint64_t *n_pairs)
+                            const uint32_t *d_sinfo, const uint32_t *d_sleaf, const uint32_t *d_multi, uint32_t tile_max,
+                            uint64_t *n_pairs)
 {
     using namespace csc;
     const size_t ctr_per_level = static_cast<size_t>(DT_SHARDS) * DT_CTR_STRIDE;
@@ -1917,6 +1918,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         q.tile_cap = tile_cap;
         q.sinfo = d_sinfo;
         q.sleaf = d_sleaf;
+        q.multi_flag = d_multi;
         int level = 0;
         bool done = false;
         // Tiles are handed to k_bp_tiles as soon as the levels the last traversal needed (+ 1) have
@@ -2101,6 +2103,8 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
         tile_max = e ? std::min<uint32_t>(static_cast<uint32_t>(std::max(0, std::atoi(e))), csc::DT_TILE_LIMIT) : 8u;
     }
     uint32_t *d_sinfo = nullptr, *d_sleaf = nullptr;
+    CSC_BUF(d_multi, uint32_t, "bvh_multi_flag", 1);
+    CSC_HIP(hipMemsetAsync(d_multi, 0, sizeof(uint32_t), ctx->stream));
     if (tile_max != 0u) {
         CSC_BUF(d_si, uint32_t, "bvh_sorted_info", static_cast<size_t>(ctx->bvh_chunks) * n);
         CSC_BUF(d_sl, uint32_t, "bvh_sorted_leaf", static_cast<size_t>(ctx->bvh_chunks) * n);
@@ -2108,14 +2112,14 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
         d_sleaf = d_sl;
     }
     KT("k_bvh_pack", hipLaunchKernelGGL(csc::k_bvh_pack, dim3(cdiv(ctx->bvh.nn_max, 256), ctx->bvh_chunks), dim3(256), 0,
-                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf));
+                                         ctx->stream, ctx->bvh, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, d_multi));
     CSC_LAUNCH_CHECK();
     ctx->bvh_packed = true;
     ctx->bp_flat = false;
     ctx->bp_node_pairs = 0;
     ctx->bp_tiles = 0;
     if (dual) {
-        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, tile_max, n_pairs);
+        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, d_multi, tile_max, n_pairs);
     }
     csc::bp_params q{};
     q.n = n;

@@ -33,6 +33,7 @@
 // distinct items are disjoint, so the processes' pair sets partition the global set.
 #pragma once
 
+#include <type_traits>
 #include "k_bvh.hpp"
 
 namespace csc
@@ -69,6 +70,7 @@ struct dual_params {
     unsigned long long *tiles;    // [DT_SHARDS][tile_cap]
     std::uint32_t *tile_cnt;      // [DT_SHARDS * DT_CTR_STRIDE]
     std::uint32_t tile_cap;
+    const std::uint32_t *multi_flag; // != 0: some leaf of the build holds several particles (k_bvh_pack)
     std::uint32_t tile_begin[DT_SHARDS]; // k_bp_tiles starts here in every shard's list (a second launch: the tiles added since)
     const std::uint32_t *sinfo;   // [C][n] orig | act << 24 | multi-leaf member << 26 (k_bvh_pack)
     const std::uint32_t *sleaf;   // [C][n] leaf of a multi-leaf member
@@ -591,7 +593,8 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
         t.iy = q.sinfo[py];
     };
     // One batch: stage the y particles, test, append the hits.
-    auto process = [&](const dt_tile_in &t) {
+    auto process = [&](const dt_tile_in &t, auto multi_c) {
+        constexpr bool MULTI = decltype(multi_c)::value;
         const bool on = xi < t.xn;
         const bool self = t.xb == t.yb;
         const std::uint32_t tix = on ? t.ix : 0u, tiy = xi < t.yn ? t.iy : 0u;
@@ -606,24 +609,33 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
             want &= static_cast<std::uint32_t>(yact >> gbase);
         }
         // A member of a multi-particle leaf anywhere in this batch: the generic test (leaf boxes).
-        const bool anym = __any(((tix | tiy) & SINFO_MULTI) != 0u);
-        if (anym) {
-            yinfo[yslot] = tiy;
+        bool anym = false;
+        if constexpr (MULTI) {
+            anym = __any(((tix | tiy) & SINFO_MULTI) != 0u);
+            if (anym) {
+                yinfo[yslot] = tiy;
+            }
         }
         wave_sync();
         std::uint32_t hits = 0;
         if (!anym) {
             // Every lane runs every test (the staging area has 64 valid slots); the comparisons
             // are wave ballots, their conjunction is scalar work.
+            // (the y boxes of step j + 1 are read from LDS while step j is tested: the slot after a
+            // tile's last one exists -- the padding, or the next tile's first)
+            float4 nl = ylb[ybase], nu = yub[ybase];
             for (std::uint32_t j = 0; j < static_cast<std::uint32_t>(TL); ++j) {
                 if (!__any(j < jhi)) {
                     break;
                 }
-                const unsigned long long m = bp_overlap_mask(t.lbx, t.ubx, ylb[ybase + j], yub[ybase + j]);
+                const float4 cl = nl, cu = nu;
+                nl = ylb[ybase + j + 1u];
+                nu = yub[ybase + j + 1u];
+                const unsigned long long m = bp_overlap_mask(t.lbx, t.ubx, cl, cu);
                 hits |= __builtin_amdgcn_inverse_ballot_w64(m) ? (1u << j) : 0u; // (one v_cndmask on the scalar mask)
             }
             hits &= want;
-        } else {
+        } else if constexpr (MULTI) {
             const std::size_t po = static_cast<std::size_t>(t.c) * q.n, no = static_cast<std::size_t>(t.c) * q.nn_max;
             float4 llx = t.lbx, lux = t.ubx;
             if (on && (tix & SINFO_MULTI)) {
@@ -669,28 +681,53 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
         }
         wave_sync(); // (the staging area is rewritten by the next batch)
     };
+    // The boxes of the batch about to be tested arrived long ago (they were requested a batch
+    // earlier), but the compiler's wait-count bookkeeping loses track of that across the loop's
+    // branches and put s_waitcnt vmcnt(0) in front of the test loop -- AFTER the next batch's
+    // loads had been issued, so that every batch waited for its successor's boxes and the
+    // prefetch hid nothing. An empty asm statement that "rewrites" the registers of the current
+    // batch BEFORE those loads are issued moves the wait to where it costs nothing; `next` (an
+    // address operand of the loads to come) keeps the scheduler from hoisting them above it.
+    auto settle = [](dt_tile_in &t, std::uint32_t &next) {
+        asm volatile(""
+                     : "+v"(t.lbx.x), "+v"(t.lbx.y), "+v"(t.lbx.z), "+v"(t.lbx.w), "+v"(t.ubx.x), "+v"(t.ubx.y), "+v"(t.ubx.z),
+                       "+v"(t.ubx.w), "+v"(t.lby.x), "+v"(t.lby.y), "+v"(t.lby.z), "+v"(t.lby.w), "+v"(t.uby.x), "+v"(t.uby.y),
+                       "+v"(t.uby.z), "+v"(t.uby.w), "+v"(t.ix), "+v"(t.iy), "+v"(next));
+    };
     // Software pipeline, unrolled by two so that no register moves are needed: the tile of batch
     // k + 2 and the boxes of batch k + 1 are in flight while batch k is tested.
-    dt_tile_in ta{}, tb{};
-    bool va, vb;
-    unsigned long long ra = rec_of(batch, va);
-    dt_tile_decode(ra, va, ta);
-    load_boxes(ta);
-    unsigned long long rb = rec_of(batch + step, vb);
-    while (batch < nbatch) {
-        dt_tile_decode(rb, vb, tb);
-        load_boxes(tb);
-        ra = rec_of(batch + 2u * step, va);
-        process(ta);
-        batch += step;
-        if (batch >= nbatch) {
-            break;
-        }
+    // Two copies of the loop: the one that runs when no leaf of this build holds more than one
+    // particle (k_bvh_pack's flag; the normal case) has no generic test in it -- whose loads,
+    // under branches, also cost the fast path its wait-count precision.
+    auto run = [&](auto multi_c) {
+        dt_tile_in ta{}, tb{};
+        bool va, vb;
+        unsigned long long ra = rec_of(batch, va);
         dt_tile_decode(ra, va, ta);
         load_boxes(ta);
-        rb = rec_of(batch + 2u * step, vb);
-        process(tb);
-        batch += step;
+        unsigned long long rb = rec_of(batch + step, vb);
+        while (batch < nbatch) {
+            dt_tile_decode(rb, vb, tb);
+            settle(ta, tb.xb);
+            load_boxes(tb);
+            ra = rec_of(batch + 2u * step, va);
+            process(ta, multi_c);
+            batch += step;
+            if (batch >= nbatch) {
+                break;
+            }
+            dt_tile_decode(ra, va, ta);
+            settle(tb, ta.xb);
+            load_boxes(ta);
+            rb = rec_of(batch + 2u * step, vb);
+            process(tb, multi_c);
+            batch += step;
+        }
+    };
+    if (*q.multi_flag != 0u) {
+        run(std::true_type{});
+    } else {
+        run(std::false_type{});
     }
     wave_sync();
     const std::uint32_t fill = *fillp;

@@ -556,7 +556,8 @@ static_assert(sizeof(tnode) == 96, "wide node layout");
 // index of their leaf (whose box, not the particle's, is what a query is tested against).
 constexpr std::uint32_t SINFO_MULTI = 1u << 26;
 CSC_GLOBAL __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_t *vidx, const std::uint8_t *active,
-                                                  tnode *tn, std::uint8_t *sact, std::uint32_t *sinfo, std::uint32_t *sleaf)
+                                                  tnode *tn, std::uint8_t *sact, std::uint32_t *sinfo, std::uint32_t *sleaf,
+                                                  std::uint32_t *multi_flag)
 {
     const std::uint32_t c = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= b.n_nodes[c]) {
@@ -594,6 +595,9 @@ CSC_GLOBAL __launch_bounds__(256) void k_bvh_pack(bvh_bufs b, const std::uint32_
             if ((k ? tag1 : tag0) < 0) {
                 const std::uint32_t lb_ = k ? b1 : b0, le_ = b.ne[no + l + k];
                 const std::uint32_t multi = le_ - lb_ > 1u ? SINFO_MULTI : 0u;
+                if (multi) {
+                    atomicOr(multi_flag, 1u); // (rare: equal Morton codes; k_bp_tiles picks its loop by it)
+                }
                 for (std::uint32_t m = lb_; m != le_; ++m) {
                     const std::uint32_t o = vx[m];
                     sinfo[po + m] = o | (static_cast<std::uint32_t>(active[o] & 3u) << 24) | multi;
