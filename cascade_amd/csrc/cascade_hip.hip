@@ -101,6 +101,7 @@ struct csc_ctx {
     uint64_t bp_tiles = 0; // tiles of the last dual traversal
     uint64_t bp_node_pairs = 0;
     int bp_mode = -1; // -1: read CASCADE_BP_MODE once; 0 per-particle walks, 1 dual traversal
+    int box_kernel = -1; // -1: read CASCADE_BOX_KERNEL once; 1: boxes of a pass with rows by k_chunk_boxes
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
@@ -687,9 +688,35 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
     return p;
 }
 
+// nobox (pass 1 with rows, order 20, built-in dynamics): the variant that leaves the per-chunk boxes
+// and samples to k_chunk_boxes.
 template <bool STORE>
-void launch_propagate(uint32_t order, int dyn, bool events, dim3 grid, dim3 block, hipStream_t stream, const csc::prop_params &p)
+void launch_propagate(uint32_t order, int dyn, bool events, dim3 grid, dim3 block, hipStream_t stream, const csc::prop_params &p,
+                      bool nobox = false)
 {
+    if constexpr (!STORE) {
+        if (nobox && order == 20u && dyn != csc::DYN_TAPE) {
+#define CSC_PROP_NOBOX_CASE(D)                                                                                         \
+    if (events) {                                                                                                      \
+        hipLaunchKernelGGL((csc::k_propagate<20, true, false, (D) | csc::DYN_NOBOX>), grid, block, 0, stream, p);      \
+    } else {                                                                                                           \
+        hipLaunchKernelGGL((csc::k_propagate<20, false, false, (D) | csc::DYN_NOBOX>), grid, block, 0, stream, p);     \
+    }
+            switch (dyn) {
+                case 0:
+                    CSC_PROP_NOBOX_CASE(0)
+                    break;
+                case 1:
+                    CSC_PROP_NOBOX_CASE(1)
+                    break;
+                default:
+                    CSC_PROP_NOBOX_CASE(3)
+                    break;
+            }
+#undef CSC_PROP_NOBOX_CASE
+            return;
+        }
+    }
     if (order != 20u) {
         // check_cfg has made sure that the order is built and that the dynamics come as a tape.
         csc_order_api(static_cast<int>(order))->propagate(STORE, events, grid, block, stream, p);
@@ -1278,8 +1305,22 @@ static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, con
             return rc;
         }
     }
-    KT(row_cap ? "k_propagate_rows" : "k_propagate", launch_propagate<false>(cfg->order, cfg->dyn_kind, events, grid, block, ctx->stream, p));
+    // With rows: the boxes and samples come from the rows, in a kernel of their own (order 20,
+    // built-in dynamics; CASCADE_BOX_KERNEL=0: fused into the integration as without rows).
+    if (ctx->box_kernel < 0) {
+        const char *e = std::getenv("CASCADE_BOX_KERNEL");
+        ctx->box_kernel = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    const bool nobox = row_cap != 0u && ctx->box_kernel == 1 && cfg->order == 20u && cfg->dyn_kind != CSC_DYN_TAPE;
+    KT(row_cap ? "k_propagate_rows" : "k_propagate",
+       launch_propagate<false>(cfg->order, cfg->dyn_kind, events, grid, block, ctx->stream, p, nobox));
     CSC_LAUNCH_CHECK();
+    if (nobox) {
+        const uint64_t lanes = static_cast<uint64_t>(n) * p.nchunks;
+        KT("k_chunk_boxes", hipLaunchKernelGGL((csc::k_chunk_boxes<20>), dim3(static_cast<uint32_t>((lanes + 255u) / 256u)), dim3(256), 0,
+                                                ctx->stream, p));
+        CSC_LAUNCH_CHECK();
+    }
     return CSC_OK;
 }
 

@@ -1386,6 +1386,14 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+    if (row_cap != 0u && (summ.flags & CSC_ST_FLAG_ROW_OVERFLOW)) {
+        // A particle took more substeps than its row slots hold. The boxes of a pass with rows may
+        // come from the rows (k_chunk_boxes) and are then incomplete for it: integrate again
+        // without rows; the rows follow in the second pass below, as in a first superstep.
+        d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
+        d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+        row_cap = 0;
+    }
     pt.lap("propagate");
     log_line(LOG_TRACE, "Propagation + AABB computation time: " + sw.elapsed() + "s");
     d.row_hint = summ.max_substeps;

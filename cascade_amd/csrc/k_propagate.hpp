@@ -42,6 +42,9 @@ enum : int {
     // General right-hand sides (the reference's heyoka expressions, sim.hpp:213-222) lowered to a
     // tape of Taylor-series operations and interpreted order by order; see tape_compute_tcs.
     DYN_TAPE = 0x100,
+    // Not a right-hand side: pass 1 writes its rows and leaves the per-chunk boxes and
+    // trajectory samples to k_chunk_boxes, which computes them from the rows.
+    DYN_NOBOX = 0x400,
 };
 
 // One tape operation (layout of csc_tape_op, include/cascade_hip.h). Slots 0..5 = x, y, z, vx,
@@ -709,8 +712,9 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
     float smp[15];
     std::uint32_t smask = 0;
     double sbound = 0., sabs = 0.;
-    const bool want_recs = !STORE && prm.recs != nullptr;
-    if constexpr (!STORE) {
+    constexpr bool BOXES = !STORE && (DYN & DYN_NOBOX) == 0;
+    const bool want_recs = BOXES && prm.recs != nullptr;
+    if constexpr (BOXES) {
         if (want_recs) {
             // Chunks that are never completed keep an invalid record (dev = +inf: never excluded).
             for (std::uint32_t k = 0; k < C; ++k) {
@@ -719,7 +723,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
             }
         }
     }
-    if constexpr (!STORE) {
+    if constexpr (BOXES) {
         // Boxes of chunks that no substep reaches stay at +-inf (:238-244).
         for (std::uint32_t k = 0; k < C; ++k) {
             float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(k) * prm.n_total + i);
@@ -729,7 +733,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
         }
     }
     auto flush_box = [&]() {
-        if constexpr (!STORE) {
+        if constexpr (BOXES) {
             if (kbox != ~0u) {
                 float4 *plo = reinterpret_cast<float4 *>(prm.lbs) + (static_cast<std::size_t>(kbox) * prm.n_total + i);
                 float4 *phi = reinterpret_cast<float4 *>(prm.ubs) + (static_cast<std::size_t>(kbox) * prm.n_total + i);
@@ -903,6 +907,8 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                         flags |= ST_FLAG_ROW_OVERFLOW;
                     }
                 }
+            }
+            if constexpr (BOXES) {
                 // Fused compute_particle_aabb (:217-395): chunks k with cb_k < tc and ce_k > tc_prev.
                 while (kc < C) {
                     const double ce = (kc == C - 1u) ? prm.delta_t : prm.ct * static_cast<double>(kc + 1u);
@@ -1026,6 +1032,153 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
         fs[3] = t.vx[0];
         fs[4] = t.vy[0];
         fs[5] = t.vz[0];
+    }
+}
+
+// The per-chunk boxes and trajectory samples of pass 1 from its rows (k_propagate<.., DYN_NOBOX>
+// wrote them into the fixed slots [i * row_cap, (i + 1) * row_cap) of particle i): the SAME
+// operations on the same coefficients as the fused code of propagate_object, so the same bits
+// (tests/test_gpu_parity.py::test_chunk_boxes_from_rows), but one lane per (particle, chunk): no
+// lane waits for another particle's substeps, and the propagation kernel (512 registers, one wave
+// per SIMD) no longer spends half of its instructions here. The lanes of a particle are
+// neighbours (chunk fastest), so the chunks of one substep read its row together.
+// A particle with more substeps than row_cap has no rows for the later ones: its boxes are
+// incomplete and the caller, who sees ST_FLAG_ROW_OVERFLOW, integrates again without rows.
+template <int P>
+__global__ __launch_bounds__(256, 2) void k_chunk_boxes(const prop_params prm)
+{
+    const std::uint32_t C = prm.nchunks;
+    const std::uint64_t g = static_cast<std::uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const std::uint32_t li = static_cast<std::uint32_t>(g / C), k = static_cast<std::uint32_t>(g % C);
+    if (li >= prm.n) {
+        return;
+    }
+    const std::uint32_t i = prm.first + li;
+    const std::uint32_t ns_all = prm.nsub[i], ns = ns_all < prm.row_cap ? ns_all : prm.row_cap;
+    const double p_radius = prm.state[static_cast<std::size_t>(i) * 7u + 6u];
+    const double infl = dmax(p_radius, prm.conj_thresh / 2);
+    const float finf = __builtin_huge_valf();
+    const bool want_recs = prm.recs != nullptr;
+    const double cb = prm.ct * static_cast<double>(k);
+    const double ce = (k == C - 1u) ? prm.delta_t : prm.ct * static_cast<double>(k + 1u);
+    constexpr int XS = tc_xyz_stride(P), VS = tc_vr_stride(P);
+    // r starts at double 3 (P + 1) of the second array; read from the even index below it.
+    constexpr int R0 = (3 * (P + 1)) & ~1, RN = VS - R0;
+
+    float blo[4] = {finf, finf, finf, finf}, bhi[4] = {-finf, -finf, -finf, -finf};
+    float smp[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) {
+        smp[q] = 0.f;
+    }
+    std::uint32_t smask = 0;
+    double sbound = 0., sabs = 0.;
+    bool visited = false, bad = false;
+    dfl tc_prev = df(0.);
+    const std::size_t row0 = static_cast<std::size_t>(i) * prm.row_cap;
+    // The fused loop visits chunk k in the substeps with ce > tc_prev and cb < tc: the substeps from
+    // the first one that ends after cb, for as long as they begin before ce. Finding the first one
+    // takes the end times only; the loop below then runs once or twice per lane with (nearly) all
+    // lanes of the wave in it (a loop over all substeps with the test inside ran at 40 % of the lanes).
+    std::uint32_t s0 = 0;
+    for (; s0 < ns; ++s0) {
+        const double2 tcv = *reinterpret_cast<const double2 *>(prm.tcoords + (row0 + s0) * 2u);
+        const dfl tc{tcv.x, tcv.y};
+        if (df_lt(df(cb), tc)) {
+            break;
+        }
+        tc_prev = tc;
+    }
+    for (std::uint32_t s = s0; s < ns && df_lt(tc_prev, df(ce)); ++s) {
+        const double2 tcv = *reinterpret_cast<const double2 *>(prm.tcoords + (row0 + s) * 2u);
+        const dfl tc{tcv.x, tcv.y};
+        {
+            visited = true;
+            double cxyz[XS], cr[RN];
+            const double2 *pxyz = reinterpret_cast<const double2 *>(prm.tcs_xyz + (row0 + s) * static_cast<std::size_t>(XS));
+#pragma unroll
+            for (int e = 0; e < XS / 2; ++e) {
+                const double2 v = pxyz[e];
+                cxyz[2 * e] = v.x;
+                cxyz[2 * e + 1] = v.y;
+            }
+            const double2 *pr2 = reinterpret_cast<const double2 *>(prm.tcs_vr + (row0 + s) * static_cast<std::size_t>(VS) + R0);
+#pragma unroll
+            for (int e = 0; e < RN / 2; ++e) {
+                const double2 v = pr2[e];
+                cr[2 * e] = v.x;
+                cr[2 * e + 1] = v.y;
+            }
+            const double *tx = cxyz, *ty = cxyz + (P + 1), *tz = cxyz + 2 * (P + 1), *tr = cr + (3 * (P + 1) - R0);
+            const dfl ev_lb = df_max(df(cb), tc_prev);
+            const dfl ev_ub = df_min(df(ce), tc);
+            const ivl hint{df_sub(ev_lb, tc_prev).hi, df_sub(ev_ub, tc_prev).hi};
+            if (want_recs) {
+                const double hs = df_sub(tc, tc_prev).hi;
+                double b2 = 0.;
+                {
+                    const double *arrs3[3] = {tx, ty, tz};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        double acc = 0.;
+#pragma unroll
+                        for (int o = P; o >= 2; --o) {
+                            acc = fma(acc, hs, static_cast<double>(o * (o - 1)) * fabs(arrs3[q][o]));
+                        }
+                        b2 = fma(acc, acc, b2);
+                    }
+                }
+                sbound = dmax(sbound, sqrt(b2));
+                const double dts = (ce - cb) * 0.25;
+#pragma unroll
+                for (int sidx = 0; sidx < 5; ++sidx) {
+                    const dfl ts = df(sidx == 4 ? ce : cb + dts * static_cast<double>(sidx));
+                    if (!df_lt(ts, tc_prev) && !df_lt(tc, ts)) {
+                        const double tau = df_sub(ts, tc_prev).hi;
+                        const double sx = horner_fma<P>(tx, tau), sy = horner_fma<P>(ty, tau), sz = horner_fma<P>(tz, tau);
+                        smp[3 * sidx] = static_cast<float>(sx);
+                        smp[3 * sidx + 1] = static_cast<float>(sy);
+                        smp[3 * sidx + 2] = static_cast<float>(sz);
+                        smask |= 1u << sidx;
+                        sabs = dmax(sabs, dmax(fabs(sx), dmax(fabs(sy), fabs(sz))));
+                    }
+                }
+            }
+            const double *arrs[4] = {tx, ty, tz, tr};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ivl v = iv_poly_eval_nonneg<P>(arrs[q], hint);
+                v.lo -= infl;
+                v.hi += infl;
+                const float fl = nextafterf(static_cast<float>(v.lo), -finf);
+                const float fu = nextafterf(static_cast<float>(v.hi), finf);
+                if (!(fabsf(fl) <= FLT_MAX) || !(fabsf(fu) <= FLT_MAX)) {
+                    bad = true;
+                }
+                blo[q] = fminf_std(blo[q], fl);
+                bhi[q] = fmaxf_std(bhi[q], fu);
+            }
+        }
+        tc_prev = tc;
+    }
+    if (bad) {
+        atomicOr(prm.status + i, ST_FLAG_BAD_AABB);
+    }
+    const std::size_t slot = static_cast<std::size_t>(k) * prm.n_total + i;
+    reinterpret_cast<float4 *>(prm.lbs)[slot] = make_float4(blo[0], blo[1], blo[2], blo[3]);
+    reinterpret_cast<float4 *>(prm.ubs)[slot] = make_float4(bhi[0], bhi[1], bhi[2], bhi[3]);
+    if (want_recs) {
+        float devf = finf; // (a chunk that is not completed keeps an invalid record: never excluded)
+        if (visited) {
+            const double dts = (ce - cb) * 0.25;
+            const double dev = sbound * dts * dts * 0.125 + p_radius + 1e-6 * sabs;
+            devf = (smask == 0x1fu && finite_d(dev)) ? nextafterf(static_cast<float>(dev), finf) : finf;
+        }
+        float4 *pr = reinterpret_cast<float4 *>(prm.recs) + slot * 4u;
+        pr[0] = make_float4(smp[0], smp[1], smp[2], smp[3]);
+        pr[1] = make_float4(smp[4], smp[5], smp[6], smp[7]);
+        pr[2] = make_float4(smp[8], smp[9], smp[10], smp[11]);
+        pr[3] = make_float4(smp[12], smp[13], smp[14], devf);
     }
 }
 

@@ -218,7 +218,9 @@ int csc_propagate(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const doubl
  * d_tcs_vr / d_tcoords (layouts as for csc_propagate_store, each array sized n * row_cap rows) and
  * d_tc_row[i] = i * row_cap. A particle that takes more than row_cap substeps sets
  * CSC_ST_FLAG_ROW_OVERFLOW in its status (csc_prop_summary.flags); the rows are then incomplete
- * and the caller falls back on csc_propagate_store. Asynchronous. */
+ * and so may be that particle's boxes and records (at order 20 with the built-in dynamics they are
+ * computed FROM the rows, by a kernel of their own, unless CASCADE_BOX_KERNEL=0): the caller falls
+ * back on csc_propagate and csc_propagate_store. Asynchronous. */
 int csc_propagate_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                        int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
                        double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,

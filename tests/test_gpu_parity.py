@@ -215,6 +215,79 @@ def _gpu_propagate(ctx, st, cfg_kw, order=None):
     return out
 
 
+def _gpu_propagate_rows(ctx, st, cfg_kw, row_cap):
+    """csc_propagate (boxes fused into the integration, no rows) and csc_propagate_rows (boxes
+    from the rows by k_chunk_boxes) on the same input: (fused, rows) dictionaries of host arrays."""
+    from cascade_amd import _capi
+
+    L, h, chk = ctx.L, ctx.h, ctx._chk
+    n = len(st)
+    cfg = _capi.PropCfg()
+    for k, v in cfg_kw.items():
+        if k == "reentry_k":
+            for i in range(3):
+                cfg.reentry_k[i] = v[i]
+        else:
+            setattr(cfg, k, v)
+    Cn = cfg.nchunks
+    d_state = ctx.array(st)
+    outs = []
+    for rows in (False, True):
+        d = dict(
+            nsub=ctx.empty(n, np.uint32),
+            status=ctx.empty(n, np.int32),
+            ev_idx=ctx.empty(n, np.uint32),
+            ev_time=ctx.empty(n, np.float64),
+            nf=ctx.empty(n, np.float64),
+            final=ctx.empty((n, 6), np.float64),
+            lbs=ctx.array(np.full((Cn, n, 4), 7.0, np.float32)),
+            ubs=ctx.array(np.full((Cn, n, 4), 7.0, np.float32)),
+            recs=ctx.array(np.full((Cn, n, 16), 7.0, np.float32)),
+        )
+        args = (h, C.byref(cfg), n, d_state.ptr, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, d["final"].ptr, d["lbs"].ptr, d["ubs"].ptr, d["recs"].ptr)
+        if rows:
+            d_row = ctx.empty(n, np.uint64)
+            d_xyz = ctx.empty((n * row_cap, 64), np.float64)
+            d_vr = ctx.empty((n * row_cap, 84), np.float64)
+            d_tco = ctx.empty((n * row_cap, 2), np.float64)
+            chk(L.csc_propagate_rows(*args, row_cap, d_row.ptr, d_xyz.ptr, d_vr.ptr, d_tco.ptr))
+        else:
+            chk(L.csc_propagate(*args))
+        chk(L.csc_sync(h))
+        outs.append({k: v.download() for k, v in d.items()})
+    return outs
+
+
+@pytest.mark.parametrize("n,ct,n_par_ct,conj,events", [(2003, 0.23, 1, 0.0, False), (2003, 0.23, 8, 0.05, False), (5000, 0.23, 3, 0.02, True), (3, 0.5, 5, 0.0, False), (1500, 0.01, 7, 0.1, True)])
+def test_chunk_boxes_from_rows(orc, ctx, n, ct, n_par_ct, conj, events):
+    """Pass 1 with rows leaves the per-chunk boxes and trajectory samples to k_chunk_boxes, which
+    computes them from the rows: the same bits as the code fused into the integration (which the
+    other tests of this file hold against the oracle), chunks never reached and chunks cut short
+    by a terminal event included."""
+    st = _pop(n)
+    kw = _cfg_kw(orc, ct, n_par_ct, conj_thresh=conj, exit_radius=1.25 if events else 0.0, reentry=1.03 if events else 0.0)
+    fused, _ = _gpu_propagate_rows(ctx, st, kw, 1)
+    cap = int(fused["nsub"].max()) + 1
+    fused, rows = _gpu_propagate_rows(ctx, st, kw, cap)
+    if events:
+        assert np.any((fused["status"] & 0xff) != 0), "some particle stops at an event"
+    for k in ("nsub", "status", "ev_idx", "lbs", "ubs"):
+        assert np.array_equal(fused[k].view(np.uint8), rows[k].view(np.uint8)), k
+    assert np.array_equal(fused["final"], rows["final"])
+    fd, rd = fused["recs"][..., 15], rows["recs"][..., 15]
+    assert np.array_equal(fd.view(np.uint32), rd.view(np.uint32)), "record radii"
+    ok = np.isfinite(fd)
+    assert ok.any()
+    assert np.array_equal(fused["recs"][ok].view(np.uint32), rows["recs"][ok].view(np.uint32)), "samples of the valid records"
+    # Too few row slots: the flag is raised, and the particles that fit are unaffected.
+    if cap > 2:
+        _, short = _gpu_propagate_rows(ctx, st, kw, cap - 2)
+        over = fused["nsub"] > cap - 2
+        assert over.any() and np.all((short["status"][over] & 0x1000) != 0) and not np.any(short["status"][~over] & 0x1000)
+        assert np.array_equal(fused["lbs"][:, ~over].view(np.uint32), short["lbs"][:, ~over].view(np.uint32))
+        assert np.array_equal(fused["ubs"][:, ~over].view(np.uint32), short["ubs"][:, ~over].view(np.uint32))
+
+
 def _cfg_kw(orc, ct, n_par_ct, conj_thresh=0.0, t0=(0.0, 0.0), exit_radius=0.0, reentry=0.0):
     kw = dict(dyn_kind=0, order=20, mu=1.0, rhofac=orc.lib().orc_rhofac(20), init_time_hi=t0[0], init_time_lo=t0[1], delta_t=ct * n_par_ct, ct=ct, nchunks=n_par_ct, max_substeps=0, conj_thresh=conj_thresh)
     kw.update(has_exit=1 if exit_radius > 0 else 0, exit_c0=exit_radius * exit_radius)
