@@ -95,8 +95,11 @@ BYTES = {
     "k_bp_dual": lambda u: u["bp_node_pairs"] * 2 * 44 + (u["bp_tiles"] * 8 if u["bp_tiles"] else u["pairs"] * 8),
     # every tile record once, every particle's box + flags once (36 B; the tiles share them), every pair out
     "k_bp_tiles": lambda u: u["bp_tiles"] * 8 + u["n"] * u["nchunks"] * 36 + u["pairs"] * 8,
-    # single-pass rows (every object's substep rows written while it is integrated)
-    "k_propagate_rows": lambda u: u["n"] * (56 + 48 + 32 * u["nchunks"] + 28 + 64 * u["nchunks"]) + u["substeps"] * (1176 + 16),
+    # single-pass rows (every object's substep rows written while it is integrated; the boxes and
+    # records are k_chunk_boxes' since round 2: state in, final state out, the rows out)
+    "k_propagate_rows": lambda u: u["n"] * (56 + 48 + 28) + u["substeps"] * (1176 + 16),
+    # the x, y, z, r series and the end time of every substep in, a box and a record per particle and chunk out
+    "k_chunk_boxes": lambda u: u["substeps"] * (4 * 21 * 8 + 16) + u["n"] * u["nchunks"] * (32 + 64),
     # every pair record read once, every trajectory record read once (the pairs of a chunk share them)
     "k_np_prefilter": lambda u: u["pairs"] * 8 + u["n"] * u["nchunks"] * 64,
     "k_rs_scatter": lambda u: u["sort_keys"] * 24,
