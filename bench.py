@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VEC_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 P = 20  # Taylor order at tol = DBL_EPSILON
 # k_bp_tiles is bound by VALU issue, not by bytes: 173 VALU wave-instructions per batch of 8 tiles
-# (SQ_INSTS_VALU / batches, profiles/r02h_pmc_tiles.txt), one wave64 VALU instruction per 4 clocks
+# (SQ_INSTS_VALU / batches, profiles/r02i_pmc_tiles.txt), one wave64 VALU instruction per 4 clocks
 # and SIMD, 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
 TILES_PER_BATCH = 8
 TILE_VALU_PER_BATCH = 182
@@ -301,7 +301,7 @@ def main():
             ginst = units["bp_tiles"] / TILES_PER_BATCH * TILE_VALU_PER_BATCH / per_step_launches / (avg_ms * 1e-3) / 1e9
             r["valu_issue"] = dict(valu_wave_instructions_per_launch=int(units["bp_tiles"] / TILES_PER_BATCH * TILE_VALU_PER_BATCH / per_step_launches),
                                    achieved_Ginst=round(ginst, 1), peak_Ginst=VALU_PEAK_GINST, frac=round(ginst / VALU_PEAK_GINST, 5),
-                                   source="182 VALU instructions per batch of 8 tiles: SQ_INSTS_VALU of profiles/r02h_pmc_tiles.txt")
+                                   source="182 VALU instructions per batch of 8 tiles: SQ_INSTS_VALU of profiles/r02i_pmc_tiles.txt")
             r.update(bound="valu_issue", hbm_frac=r["frac"], hbm_achieved_GBps=r["achieved"], achieved=round(ginst, 1), peak=VALU_PEAK_GINST,
                      unit="G wave-instructions/s", frac=round(ginst / VALU_PEAK_GINST, 5))
         t = measured_traffic(name, workload)

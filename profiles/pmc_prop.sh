@@ -31,6 +31,6 @@ for sub in ('sq','sq2','f64'):
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
         if (r['Dispatch_Id']) not in seen: seen.add(r['Dispatch_Id']); cnt[k]+=1
     for kk in sorted(agg):
-        if kk.startswith(('k_propagate','k_np_roots','k_np_fex')):
+        if kk.startswith(('k_propagate','k_chunk_boxes','k_np_roots','k_np_fex')):
             print(sub,kk,"dispatches",cnt[kk],{c:round(v) for c,v in sorted(agg[kk].items())})
 PY
