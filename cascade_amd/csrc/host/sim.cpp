@@ -1321,6 +1321,9 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler || from_tape)
         && d.row_hint != 0u) {
         row_cap = d.row_hint + std::max(2u, d.row_hint / 4u);
+        if (const char *e = std::getenv("CASCADE_ROW_CAP")) {
+            row_cap = std::max(1, std::atoi(e)); // (tests: slots that overflow)
+        }
         if (static_cast<double>(n) * row_cap * (xs + vs + 2u) * 8. > 96e9) {
             row_cap = 0; // would not fit comfortably: two passes
         }

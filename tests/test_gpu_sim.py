@@ -346,6 +346,47 @@ def test_single_pass_rows_change_nothing(kind, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["kepler", "j2drag"])
+def test_row_overflow_falls_back(kind, monkeypatch):
+    """A particle that takes more substeps than it has row slots: its rows, and the boxes computed
+    from them (k_chunk_boxes), are incomplete; the superstep is integrated again without rows and
+    gives the same events and states as a run whose slots suffice."""
+    from cascade_amd import _capi, dynamics, sim
+    from cascade_amd.workloads import leo_si_population, random_leo_pop_kep
+
+    if kind == "kepler":
+        st = random_leo_pop_kep(20000, seed=5)
+        st[:, 6] *= 3e3
+        args, kw = (st, 0.23), dict(n_par_ct=8, conj_thresh=2e-3)
+    else:
+        st, pars = leo_si_population(5000, seed=3)
+        st[:, 6] *= 200.0
+        args, kw = (st, 185.5663), dict(dyn=dynamics.simple_earth(C22S22=False), pars=pars, n_par_ct=6, conj_thresh=20e3)
+    monkeypatch.setenv("CASCADE_ROWS_ON_DEMAND", "0")  # (Kepler: rows for every particle, written in pass 1)
+    a = sim(args[0].copy(), args[1], **kw)
+    monkeypatch.setenv("CASCADE_ROW_CAP", "1")
+    b = sim(args[0].copy(), args[1], **kw)
+    ctx = _capi.Context.from_handle(b._hip_context)
+    ctx.profile(True)
+    n_events = 0
+    for _ in range(3):
+        oa, ob = a.step(), b.step()
+        assert oa == ob and a.interrupt_info == b.interrupt_info
+        assert a.last_collisions.tobytes() == b.last_collisions.tobytes()
+        assert a.last_step_conjunctions.tobytes() == b.last_step_conjunctions.tobytes()
+        assert np.array_equal(a.state, b.state) and a.time == b.time
+        n_events += len(a.last_collisions) + len(a.last_step_conjunctions)
+        if oa.name in ("reentry", "collision"):
+            ii = a.interrupt_info
+            for s in (a, b):
+                s.remove_particles([ii] if isinstance(ii, int) else list(ii))
+    prof = ctx.profile_get()
+    # supersteps 2 and 3 tried rows (one slot each), overflowed and were integrated again without
+    assert prof["k_propagate_rows"][0] >= 2 and prof["k_chunk_boxes"][0] >= 2 and prof["k_propagate"][0] >= 3, {k: v[0] for k, v in prof.items() if "propagate" in k or "boxes" in k}
+    assert n_events > 0
+
+
+@pytest.mark.gpu
 def test_broad_phase_formulations_agree(monkeypatch):
     """The dual traversal (default) and the per-particle cooperative walks (fallback for trees
     beyond the dual traversal's item encoding, CASCADE_BP_MODE=walk) give the same pairs, events
