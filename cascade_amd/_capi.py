@@ -98,7 +98,7 @@ SYMBOLS = {
     "csc_memcpy_d2d": (_i32, [_vp, _vp, _vp, _sz]),
     "csc_upload": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(_u64)]),
     "csc_download": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(_u64)]),
-    "csc_host_hash": (_u64, [_vp, _sz]),
+    "csc_host_hash": (None, [_vp, _sz, C.POINTER(_u64)]),
     "csc_memset": (_i32, [_vp, _vp, _i32, _sz]),
     "csc_sync": (_i32, [_vp]),
     "csc_timer_begin": (_i32, [_vp]),

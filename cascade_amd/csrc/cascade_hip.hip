@@ -948,15 +948,43 @@ namespace
 
 constexpr unsigned XFER_CHUNKS = 16, XFER_THREADS = 8;
 
-// Position-dependent sum hash of 8-byte words (order-independent, so chunks combine by addition).
-inline uint64_t hash_words(const unsigned char *p, size_t first_word, size_t nwords)
+// 128-bit position-dependent checksum of 8-byte words. Every word goes through a full avalanche
+// (two different multiply / xor-shift finalisers of the word combined with its position) BEFORE it
+// is added to the two 64-bit lanes, so a structured edit -- an even number of sign flips, +d / -d on
+// two words, two rows swapped -- changes each lane by a sum of pseudo-random 64-bit terms that
+// cancels with probability 2^-64 per lane (2^-128 for both). The sums are order-independent, so
+// the chunks of a transfer combine by addition. (Round 2 added (w ^ k) * odd without the avalanche:
+// linear mod 2^64, blind to any even number of bit-63 flips.)
+struct hash128 {
+    uint64_t a = 0, b = 0;
+    void operator+=(const hash128 &o)
+    {
+        a += o.a;
+        b += o.b;
+    }
+};
+
+extern "C++" inline hash128 hash_words(const unsigned char *p, size_t first_word, size_t nwords)
 {
-    uint64_t h = 0;
+    hash128 h;
     for (size_t i = 0; i < nwords; ++i) {
         uint64_t w;
         std::memcpy(&w, p + i * 8u, 8);
-        const uint64_t k = (first_word + i) * 0x9e3779b97f4a7c15ull;
-        h += (w ^ k) * 0xff51afd7ed558ccdull + (k >> 29);
+        const uint64_t k = (first_word + i + 1u) * 0x9e3779b97f4a7c15ull;
+        uint64_t x = w ^ k; // murmur3's fmix64
+        x ^= x >> 33;
+        x *= 0xff51afd7ed558ccdull;
+        x ^= x >> 33;
+        x *= 0xc4ceb9fe1a85ec53ull;
+        x ^= x >> 33;
+        uint64_t y = w + (k ^ 0x2545f4914f6cdd1dull); // splitmix64's finaliser, other constants
+        y ^= y >> 30;
+        y *= 0xbf58476d1ce4e5b9ull;
+        y ^= y >> 27;
+        y *= 0x94d049bb133111ebull;
+        y ^= y >> 31;
+        h.a += x;
+        h.b += y;
     }
     return h;
 }
@@ -989,11 +1017,11 @@ int xfer_prepare(csc_ctx *ctx, size_t bytes)
 
 } // namespace
 
-uint64_t csc_host_hash(const void *p, size_t bytes)
+void csc_host_hash(const void *p, size_t bytes, uint64_t out[2])
 {
     const size_t nwords = bytes / 8u;
     const unsigned nt = nwords < (1u << 16) ? 1u : std::max(1u, std::min(XFER_THREADS, std::thread::hardware_concurrency()));
-    std::vector<uint64_t> part(nt, 0);
+    std::vector<hash128> part(nt);
     const size_t per = (nwords + nt - 1) / nt;
     auto work = [&](unsigned t) {
         const size_t b = std::min(nwords, t * per), e = std::min(nwords, b + per);
@@ -1007,24 +1035,31 @@ uint64_t csc_host_hash(const void *p, size_t bytes)
     for (auto &t : th) {
         t.join();
     }
-    uint64_t h = 0;
-    for (uint64_t v : part) {
+    hash128 h;
+    for (const hash128 &v : part) {
         h += v;
     }
-    return h;
+    // (the trailing bytes of an array that is not a multiple of 8 long: one zero-padded word)
+    if (bytes % 8u != 0u) {
+        unsigned char tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::memcpy(tail, static_cast<const unsigned char *>(p) + nwords * 8u, bytes % 8u);
+        h += hash_words(tail, nwords, 1);
+    }
+    out[0] = h.a;
+    out[1] = h.b;
 }
 
-int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_t *hash)
+int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_t hash[2])
 {
     if (hash) {
-        *hash = 0;
+        hash[0] = hash[1] = 0;
     }
     if (bytes == 0) {
         return CSC_OK;
     }
     if (bytes < (4u << 20) || bytes % 8u != 0u) {
         if (hash) {
-            *hash = csc_host_hash(src, bytes);
+            csc_host_hash(src, bytes, hash);
         }
         return csc_memcpy_h2d(ctx, d_dst, src, bytes);
     }
@@ -1035,7 +1070,7 @@ int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_
     CSC_HIP(hipStreamSynchronize(ctx->stream));
     const size_t nwords = bytes / 8u, per = (nwords + XFER_CHUNKS - 1) / XFER_CHUNKS;
     const unsigned nt = std::max(1u, std::min(XFER_THREADS, std::thread::hardware_concurrency()));
-    std::vector<uint64_t> part(XFER_CHUNKS, 0);
+    std::vector<hash128> part(XFER_CHUNKS);
     std::vector<hipError_t> err(nt, hipSuccess);
     auto work = [&](unsigned t) {
         (void)hipSetDevice(ctx->device);
@@ -1071,17 +1106,20 @@ int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_
         }
     }
     if (hash) {
-        for (uint64_t v : part) {
-            *hash += v;
+        hash128 h;
+        for (const hash128 &v : part) {
+            h += v;
         }
+        hash[0] = h.a;
+        hash[1] = h.b;
     }
     return CSC_OK;
 }
 
-int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint64_t *hash)
+int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint64_t hash[2])
 {
     if (hash) {
-        *hash = 0;
+        hash[0] = hash[1] = 0;
     }
     if (bytes == 0) {
         return CSC_OK;
@@ -1089,7 +1127,7 @@ int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint6
     if (bytes < (4u << 20) || bytes % 8u != 0u) {
         const int rc = csc_memcpy_d2h(ctx, dst, d_src, bytes);
         if (rc == CSC_OK && hash) {
-            *hash = csc_host_hash(dst, bytes);
+            csc_host_hash(dst, bytes, hash);
         }
         return rc;
     }
@@ -1109,7 +1147,7 @@ int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint6
         CSC_HIP(hipEventRecord(ctx->stage_ev[c], ctx->copy_stream));
     }
     const unsigned nt = std::max(1u, std::min(XFER_THREADS, std::thread::hardware_concurrency()));
-    std::vector<uint64_t> part(XFER_CHUNKS, 0);
+    std::vector<hash128> part(XFER_CHUNKS);
     std::vector<hipError_t> err(nt, hipSuccess);
     auto work = [&](unsigned t) {
         (void)hipSetDevice(ctx->device);
@@ -1144,9 +1182,12 @@ int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint6
         }
     }
     if (hash) {
-        for (uint64_t v : part) {
-            *hash += v;
+        hash128 h;
+        for (const hash128 &v : part) {
+            h += v;
         }
+        hash[0] = h.a;
+        hash[1] = h.b;
     }
     return CSC_OK;
 }

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <ctime>
 #include <limits>
 #include <map>
@@ -443,7 +444,7 @@ struct sim::sim_data {
     // Hashes of the host state / parameter vectors as of the last transfer (csc_upload /
     // csc_download): when they still match at the next step(), the caller has not edited the
     // arrays and the device copies are current.
-    std::uint64_t state_hash = 0, pars_hash = 0;
+    std::uint64_t state_hash[2] = {0, 0}, pars_hash[2] = {0, 0};
     bool hash_valid = false;
     std::uint64_t step_counter = 0; // step() calls so far (identical on the processes of a sharded simulation)
     std::vector<std::pair<std::uint64_t, std::uint64_t>> conj_segments;
@@ -1032,13 +1033,13 @@ void sim::upload_state()
     d.ensure_ctx();
     const auto n = get_nparts();
     double *d_state = d.buf<double>("state", n * 7u);
-    d.state_hash = d.pars_hash = 0;
+    d.state_hash[0] = d.state_hash[1] = d.pars_hash[0] = d.pars_hash[1] = 0;
     if (n) {
-        d.chk(csc_upload(d.ctx, d_state, m_state->data(), n * 7u * sizeof(double), &d.state_hash));
+        d.chk(csc_upload(d.ctx, d_state, m_state->data(), n * 7u * sizeof(double), d.state_hash));
     }
     if (m_npars != 0u && n) {
         double *d_pars = d.buf<double>("pars", n * m_npars);
-        d.chk(csc_upload(d.ctx, d_pars, m_pars->data(), n * m_npars * sizeof(double), &d.pars_hash));
+        d.chk(csc_upload(d.ctx, d_pars, m_pars->data(), n * m_npars * sizeof(double), d.pars_hash));
     }
     d.hash_valid = true;
     d.dev_rows = static_cast<std::int64_t>(n);
@@ -1055,7 +1056,7 @@ void sim::download_state()
     // One copy of the whole [n][7] array: the sizes on the device are the host's as of the last
     // upload (only the six coordinates are outputs of a step, copy_from_final_state :1610-1630).
     if (n) {
-        d.chk(csc_download(d.ctx, m_state->data(), d.buf<double>("state", n * 7u), n * 7u * sizeof(double), &d.state_hash));
+        d.chk(csc_download(d.ctx, m_state->data(), d.buf<double>("state", n * 7u), n * 7u * sizeof(double), d.state_hash));
     }
 }
 
@@ -1159,8 +1160,10 @@ outcome sim::step()
         struct stale_state {
         };
         std::future<bool> same = std::async(std::launch::async, [&]() {
-            return csc_host_hash(m_state->data(), m_state->size() * sizeof(double)) == d.state_hash
-                   && csc_host_hash(m_pars->data(), m_pars->size() * sizeof(double)) == d.pars_hash;
+            std::uint64_t hs[2], hp[2];
+            csc_host_hash(m_state->data(), m_state->size() * sizeof(double), hs);
+            csc_host_hash(m_pars->data(), m_pars->size() * sizeof(double), hp);
+            return hs[0] == d.state_hash[0] && hs[1] == d.state_hash[1] && hp[0] == d.pars_hash[0] && hp[1] == d.pars_hash[1];
         });
         bool checked = false, unchanged = false;
         const auto check = [&]() {
@@ -1471,6 +1474,23 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     const bool have_chunks = cl != 0u;
 
     sw = stopwatch{};
+    const std::uint64_t tot = summ.total_substeps;
+    d.last_cfg = cfg;
+    std::uint64_t npairs = 0;
+    std::uint64_t ncoll = 0, nconj = 0;
+    std::uint32_t warn = 0, np_attempts = 0;
+    const csc_collision *coll_p = nullptr;
+    const csc_conjunction *conj_p = nullptr;
+    std::uint64_t ncoll_v = 0, nconj_v = 0;
+    // Everything between the integration and the summary exchange works on THIS process's chunks
+    // when the chunks are dealt out, so an error in it is local: it is caught, carried through
+    // the exchange as a code, and raised on every process afterwards (a process that threw here
+    // would leave the others waiting in the all-gather forever).
+    struct nonfinite_gaabb : std::invalid_argument {
+        using std::invalid_argument::invalid_argument;
+    };
+    static const char *const gaabb_msg = "A global bounding box with non-finite boundaries and/or size was generated";
+    const auto local_stages = [&]() {
     if (have_chunks) {
         d.chk(csc_global_aabb(ctx, n, cl, d_lbs, d_ubs, d_glb, d_gub));
         d.chk(csc_morton_encode(ctx, n, cl, d_lbs, d_ubs, d_glb, d_gub, d_codes));
@@ -1482,8 +1502,6 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         log_line(LOG_TRACE, "Morton encoding and sorting time: " + sw.elapsed() + "s");
         sw = stopwatch{};
     }
-    const std::uint64_t tot = summ.total_substeps;
-    d.last_cfg = cfg;
     if (have_chunks) {
         d.chk(csc_bvh_build(ctx, n, cl, d_scodes, d_slbs, d_subs));
     }
@@ -1492,7 +1510,6 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         log_line(LOG_TRACE, "BVH construction time: " + sw.elapsed() + "s");
         sw = stopwatch{};
     }
-    std::uint64_t npairs = 0;
     if (chunk_mode) {
         d.chk(csc_set_shard(ctx, 0u, 1u));
     } else {
@@ -1511,13 +1528,11 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     {
         const int rc = csc_check_flags(ctx);
         if (rc == CSC_ERR_NONFINITE_AABB) {
-            throw std::invalid_argument("A global bounding box with non-finite boundaries and/or size was generated");
+            throw nonfinite_gaabb(gaabb_msg);
         }
         d.chk(rc);
     }
     pt.lap("sort/bvh/bp");
-    std::uint64_t ncoll = 0, nconj = 0;
-    std::uint32_t warn = 0, np_attempts = 0;
     d.stats.stored_objects = n;
     // Taylor coefficients for dense output when the integration did not write them: exact-fit CSR
     // rows, of every particle in the Morton order of chunk 0 (two-pass mode), or only of the
@@ -1573,13 +1588,31 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     // The event lists stay in the context (pinned host memory; a conjunction-heavy superstep
     // yields millions of 128-byte records): no copies besides the append to m_det_conj below.
-    const csc_collision *coll_p = nullptr;
-    const csc_conjunction *conj_p = nullptr;
-    std::uint64_t ncoll_v = 0, nconj_v = 0;
     if (have_chunks) {
         d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
     }
     pt.lap("narrow");
+    };
+    std::exception_ptr local_err;
+    std::uint64_t local_code = 0;
+    if (d.shard_n > 1u) {
+        try {
+            local_stages();
+        } catch (const nonfinite_gaabb &) {
+            local_err = std::current_exception();
+            local_code = 1;
+        } catch (...) {
+            local_err = std::current_exception();
+            local_code = 2;
+        }
+        if (local_err) {
+            ncoll_v = nconj_v = 0;
+            coll_p = nullptr;
+            conj_p = nullptr;
+        }
+    } else {
+        local_stages();
+    }
     if (tracing) {
         // src/sim_narrow_phase.cpp:1017-1021
         log_line(LOG_TRACE, "Narrow phase collision detection time: " + sw.elapsed() + "s");
@@ -1620,7 +1653,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         shard_summary mine;
         mine.n_coll = ncoll_v;
         mine.n_conj = nconj_v;
-        mine.n_cand = ncand_all;
+        mine.n_cand = (ncand_all & 0x00ffffffffffffffull) | (local_code << 56); // (top byte: this process's error code)
         if (ncoll_v) {
             mine.coll_i = coll[0].i;
             mine.coll_j = coll[0].j;
@@ -1632,10 +1665,27 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
             throw std::runtime_error("sharded simulation: the exchange returned " + std::to_string(all.size())
                                      + " summaries for " + std::to_string(d.shard_n) + " processes");
         }
+        for (std::size_t r = 0; r < all.size(); ++r) {
+            const std::uint64_t code = all[r].n_cand >> 56;
+            if (code == 0u) {
+                continue;
+            }
+            // Some process failed in its share of the superstep: the same kind of exception on
+            // every process, nothing user-visible has changed yet (strong guarantee as in the
+            // unsharded step, src/sim_propagate.cpp:513-515).
+            if (local_err) {
+                std::rethrow_exception(local_err);
+            }
+            if (code == 1u) {
+                throw std::invalid_argument(gaabb_msg);
+            }
+            throw std::runtime_error("sharded simulation: process " + std::to_string(r)
+                                     + " failed in its share of the superstep (its own exception has the reason)");
+        }
         coll.clear();
         ncand_all = 0;
         for (const auto &s : all) {
-            ncand_all += s.n_cand;
+            ncand_all += s.n_cand & 0x00ffffffffffffffull;
             if (s.n_coll) {
                 const csc_collision c{s.coll_i, s.coll_j, s.coll_time};
                 if (coll.empty() || std::tie(c.time, c.i, c.j) < std::tie(coll[0].time, coll[0].i, coll[0].j)) {

@@ -709,10 +709,16 @@ __global__ __launch_bounds__(NP_FLAT_BLOCK) void k_np_prefilter_flat(const np_pa
             }
         }
         __syncthreads();
-        if (s_n > NP_FLAT_TILE) { // (uniform: s_n is stable between the barriers)
+        // Every thread reads the count BEFORE any thread can start the next tile's appends (a
+        // faster wave's atomicAdd would otherwise split the workgroup's decision: mismatched
+        // barriers inside flush(), lost candidates).
+        const bool do_flush = s_n > NP_FLAT_TILE;
+        __syncthreads();
+        if (do_flush) {
             flush();
         }
     }
+    // (after the loop's last barrier nobody writes s_n any more: uniform)
     if (s_n != 0u) {
         flush();
     }

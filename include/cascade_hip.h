@@ -173,12 +173,16 @@ int csc_memcpy_d2d(csc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); 
  * through a pinned staging mirror in the context, chunk by chunk, several host threads next to the
  * DMA: ~3x the rate of a plain hipMemcpy of pageable memory. csc_upload returns once src has been
  * read (the device copy is ordered on the context's stream); csc_download is synchronous and
- * ordered after everything queued on the stream. hash (may be NULL) receives csc_host_hash of the
- * host array, computed on the way: the simulation compares it at the next step() to know whether
- * its caller edited the array in between. */
-int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_t *hash);
-int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint64_t *hash);
-uint64_t csc_host_hash(const void *p, size_t bytes); /* multi-threaded, position-dependent 64-bit hash; no device involved */
+ * ordered after everything queued on the stream. hash (two words; may be NULL) receives
+ * csc_host_hash of the host array, computed on the way: the simulation compares it at the next
+ * step() to know whether its caller edited the array in between. */
+int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_t hash[2]);
+int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint64_t hash[2]);
+/* Multi-threaded 128-bit position-dependent checksum of a host array; no device involved. Every
+ * 8-byte word is avalanched together with its position (two different 64-bit finalisers) before
+ * it is summed into the two lanes: an edit is missed with probability 2^-128 whatever its
+ * structure (sign flips, swapped rows, +d / -d). */
+void csc_host_hash(const void *p, size_t bytes, uint64_t out[2]);
 int csc_memset(csc_ctx *ctx, void *d_dst, int value, size_t bytes);           /* async */
 int csc_sync(csc_ctx *ctx);
 /* HIP-event stopwatch on the context's stream: ms between begin and end. */

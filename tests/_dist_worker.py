@@ -194,6 +194,35 @@ def main():
             assert np.array_equal(full.state, part.state) and full.time == part.time
             assert part.last_propagated <= -(-301 // world)
         print("simprop ok", rank)
+    elif mode == "simerr":
+        # An error that only ONE process can see -- the global box of chunk 1 overflows f32, the
+        # one of chunk 0 does not, and the chunks are dealt to the processes -- must be raised on
+        # every process (it travels as a code in the summary exchange); before, the process that
+        # threw left the other one waiting in the all-gather forever.
+        from cascade_amd import sim
+        from cascade_amd.parallel import shard
+        from cascade_amd.workloads import random_leo_pop_kep
+
+        st = random_leo_pop_kep(500, seed=4)
+        st[0, :6] = [-1.5e38, 0, 0, 0, 0, 0]  # far away, at rest
+        st[1, :6] = [1e37, 0, 0, 5e38, 0, 0]  # chunk 0: x up to 1.25e38 (extent 2.75e38 < FLT_MAX), chunk 1: 2.4e38 (3.9e38: inf)
+        full = sim(st.copy(), 0.23, n_par_ct=2, device=dev)
+        part = shard(sim(st.copy(), 0.23, n_par_ct=2, device=dev), propagation=True)
+        msg = "A global bounding box with non-finite boundaries and/or size was generated"
+        for s in (full, part):
+            before, t0 = np.array(s.state), s.time
+            try:
+                s.step()
+                raise AssertionError("no exception on rank %d" % rank)
+            except ValueError as e:
+                assert msg in str(e), str(e)
+            assert np.array_equal(s.state, before) and s.time == t0
+        # ... and the simulation is usable afterwards (same calls on every process).
+        st2 = random_leo_pop_kep(500, seed=4)
+        full.set_new_state_pars(st2.copy())
+        part.set_new_state_pars(st2.copy())
+        assert full.step() == part.step() and np.array_equal(full.state, part.state)
+        print("simerr ok", rank)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -142,3 +142,51 @@ def test_refit_handoff_isa():
     # there is a wait for all outstanding vector memory operations.
     assert mem[atom[0] - 1].startswith("s_waitcnt vmcnt(0)"), mem[: atom[0] + 1]
     assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in body), "no cache-wide fences"
+
+
+def test_host_hash_sees_structured_edits():
+    """csc_host_hash is what sim::step() uses to decide that nobody edited the host arrays
+    (cascade.py/core.cpp:199-230 hands out writable views). Round 2's hash was a linear sum mod
+    2^64: blind to an even number of sign flips (time reversal `state[:, 3:6] *= -1`), to +d / -d
+    on two words and, with bad luck, to swapped rows. Every word is avalanched with its position
+    now; each of these edits must change BOTH 64-bit lanes."""
+    import ctypes as C
+
+    import numpy as np
+
+    import __graft_entry__ as g
+
+    g.build_hip()
+    from cascade_amd import _capi
+
+    L = _capi.lib()
+
+    def h(a):
+        a = np.ascontiguousarray(a)
+        out = (C.c_uint64 * 2)()
+        L.csc_host_hash(a.ctypes.data_as(C.c_void_p), a.nbytes, out)
+        return (int(out[0]), int(out[1]))
+
+    rng = np.random.default_rng(5)
+    for n in (2, 1000, 200000):  # one thread and several (>= 65536 words)
+        st = rng.normal(size=(n, 7))
+        st[:, 6] = np.abs(st[:, 6])
+        base = h(st)
+        assert base == h(st.copy()), "deterministic, independent of the address"
+        edits = []
+        a = st.copy(); a[:, 3:6] *= -1; edits.append(a)  # 3n sign flips: even for every n here
+        a = st.copy(); a[0, 0] *= -1; a[0, 1] *= -1; edits.append(a)
+        a = st.copy(); a[[0, n - 1]] = a[[n - 1, 0]]; edits.append(a)  # two rows swapped
+        a = st.copy().view(np.uint64); a[0, 0] += 1 << 40; a[1, 0] -= 1 << 40; edits.append(a.view(np.float64))
+        a = st.copy().view(np.uint64); a[0, 2] ^= 1 << 62; a[n - 1, 2] ^= 1 << 62; edits.append(a.view(np.float64))
+        a = st.copy(); a[n // 2, 4] = np.nextafter(a[n // 2, 4], 9.0); edits.append(a)  # one ulp
+        seen = {base}
+        for e in edits:
+            he = h(e)
+            assert he[0] != base[0] and he[1] != base[1], (n, he, base)
+            seen.add(he)
+        assert len(seen) == len(edits) + 1
+    # chunks combine by addition: the transfer paths hash piecewise
+    assert h(np.zeros(3)) != h(np.zeros(4)) and h(np.zeros(0)) == (0, 0)
+    b = np.frombuffer(bytes(range(20)), dtype=np.uint8)  # a tail that is not a multiple of 8
+    assert h(b) != h(b[:16]) and h(b) != h(np.concatenate([b[:19], [0]]).astype(np.uint8))

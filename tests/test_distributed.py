@@ -58,6 +58,14 @@ def test_sharded_propagation_matches_unsharded():
     _run_world("simprop", world=3)
 
 
+@pytest.mark.gpu
+def test_local_error_is_raised_on_every_rank():
+    """A non-finite global box in the chunk block of one process only: both processes raise the
+    reference's ValueError (src/sim_propagate.cpp:453-456) instead of one hanging in the
+    collective."""
+    _run_world("simerr", world=2, timeout=120)
+
+
 def _gpus():
     import torch
 
@@ -70,6 +78,7 @@ def test_sharded_sim_rccl():
     least two GPUs; skipped on a one-GPU box (where the gloo tests above cover the logic)."""
     if _gpus() < 2:
         pytest.skip("needs >= 2 GPUs: backend nccl (RCCL) with one GPU per rank")
-    world = min(_gpus(), 3)
+    world = min(_gpus(), 8)
     _run_world("sim", world=world, backend="nccl")
     _run_world("simprop", world=world, backend="nccl")
+    _run_world("simerr", world=2, backend="nccl")

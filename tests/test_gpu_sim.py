@@ -575,6 +575,48 @@ def test_host_edits_between_steps_are_honoured_without_any_flag():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 1000, 120000])
+def test_structured_host_edits_are_honoured(n):
+    """Edits that a linear checksum cannot see (round 2's missed all four): (a) time reversal
+    `state[:, 3:6] *= -1` with 3n even, (b) two rows swapped, (c) +d / -d on two words, (d) sign
+    flips of two parameters. Default mode, no flag: after the next step the state must be, bit for
+    bit, that of a fresh simulation started from the edited arrays
+    (cascade.py/core.cpp:199-230, benchmark/haumea.cpp:203-212)."""
+    from cascade_amd import dynamics, sim
+    from cascade_amd.workloads import leo_si_population
+
+    st, pars = leo_si_population(n, seed=33)
+    kw = dict(dyn=dynamics.simple_earth(J2=True, C22S22=False, drag=True), n_par_ct=2)
+    a = sim(st.copy(), 185.5663, pars=pars.copy(), **kw)
+    view, pview = a.state, a.pars
+    a.step()
+
+    def edit_a():
+        view[:, 3:6] *= -1
+
+    def edit_b():
+        view[[0, n - 1]] = view[[n - 1, 0]]
+        pview[[0, n - 1]] = pview[[n - 1, 0]]
+
+    def edit_c():
+        u = view.view(np.uint64)
+        u[0, 0] += 1 << 30
+        u[1, 0] -= 1 << 30
+
+    def edit_d():
+        pview[0, 0] *= -1
+        pview[n - 1, 0] *= -1
+
+    for edit in (edit_a, edit_b, edit_c, edit_d):
+        edit()
+        c = sim(np.array(view), 185.5663, pars=np.array(pview), **kw)
+        c.time = a.time
+        assert a.step() == c.step(), edit.__name__
+        assert np.array_equal(a.state, c.state), edit.__name__
+        assert a.step() == c.step() and np.array_equal(a.state, c.state), "and an unedited step after it"
+
+
+@pytest.mark.gpu
 def test_trace_log_lines(capfd):
     """At trace level step() prints the reference's per-phase lines (sample in
     cascade.py/docstrings.cpp:581-596), including the tuning signal "Average number of AABB
