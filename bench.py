@@ -140,9 +140,17 @@ def main():
                     help="N > 1: every rank integrates all objects (no all-gather of the per-object records)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process (which has made no GPU call)
+        # starts the N ranks itself, relays rank 0's JSON line and fails if any rank fails.
+        sys.exit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # (a line that says n_gpus = N must come from N ranks)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report one as the other" % (args.gpus, world))
     dist = None
     backend = None
     if world > 1:
@@ -157,6 +165,8 @@ def main():
         dist_.init_process_group(backend=backend)
         dist = dist_
         tdev = "cuda" if backend == "nccl" else "cpu"
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     from cascade_amd import _capi, sim
     from cascade_amd.workloads import random_leo_pop_kep
@@ -346,7 +356,7 @@ def main():
             "n_par_ct": args.n_par_ct,
             "parallelism": parallelism,
             "backend": backend,
-            "ranks": world,
+            "ranks": dist.get_world_size() if dist is not None else 1,  # what the process group (RCCL) saw
             "propagated_per_rank": per_rank_prop,
             "exchange_bytes_received_per_step_rank0": int(s.last_exchanged_bytes),
             "bp_pairs_per_step_per_rank": per_rank_pairs,
@@ -398,6 +408,56 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """One child process per GPU with the torch.distributed environment set (rendezvous on
+    127.0.0.1, a free port), the same command line. Rank 0's stdout is relayed (the JSON line); the
+    other ranks' output goes to stderr. Returns non-zero if any rank failed, after ending the rest."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = got[0] if got else ""
+    lines = [l for l in (out0 or "").splitlines() if l.strip()]
+    if rc == 0 and not any(l.startswith("{") for l in lines):
+        rc = 1
+    for l in lines:
+        print(l)
+    if rc != 0:
+        print("bench.py: a rank failed (exit code %d)" % rc, file=sys.stderr)
+    return rc
 
 
 def cpu_baseline(args, st_w, t_w, gpu_pairs_by_step):

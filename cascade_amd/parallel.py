@@ -35,12 +35,28 @@ def make_summary_exchange(group=None, device=None):
     world = dist.get_world_size(group)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    device = torch.device(device)
+    # Persistent buffers: nothing is allocated per superstep. With RCCL the 48 bytes go through a
+    # pinned host pair and a device pair that live as long as the exchange does.
     recv = torch.empty(world * 6, dtype=torch.int64, device=device)  # flat: what gloo accepts too
+    send = torch.empty(6, dtype=torch.int64, device=device)
+    on_device = device.type == "cuda"
+    if on_device:
+        send_h = torch.empty(6, dtype=torch.int64).pin_memory()
+        recv_h = torch.empty(world * 6, dtype=torch.int64).pin_memory()
+    else:
+        send_h, recv_h = send, recv
+    send_np, recv_np = send_h.numpy(), recv_h.numpy().reshape(world, 6)
 
     def exchange(local):
-        send = torch.from_numpy(np.ascontiguousarray(local, dtype=np.int64)).to(device)
+        send_np[:] = np.asarray(local, dtype=np.int64)
+        if on_device:
+            send.copy_(send_h, non_blocking=True)
         dist.all_gather_into_tensor(recv, send, group=group)
-        return recv.cpu().numpy().reshape(world, 6)
+        if on_device:
+            recv_h.copy_(recv, non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+        return recv_np.copy()
 
     return exchange
 

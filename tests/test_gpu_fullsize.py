@@ -182,3 +182,142 @@ def test_supersteps_1m(orc, pop, monkeypatch):
     for _ in range(3):
         assert o.step() == "success"
     assert np.all(np.abs(a.state[idx] - o.state) <= 1e-9 * np.maximum(1.0, np.abs(o.state)))
+
+
+def test_bench_configuration_1m_8_chunks(orc, pop, monkeypatch):
+    """bench.py's own configuration: 1M objects, ct = 0.23, n_par_ct = 8. At 8 chunks step() takes
+    another path than at 1 (rows written during the integration, the boxes of all chunks from the
+    rows by k_chunk_boxes, 8-chunk sort / tree / traversal / tile launches, store pass for
+    everybody). Stage invariants per chunk through the C ABI, then whole supersteps."""
+    from cascade_amd import _capi, sim
+
+    Cn, n = 8, N
+    ctx = _capi.Context(0)
+    L, h, chk = ctx.L, ctx.h, ctx._chk
+    cfg = _capi.PropCfg()
+    for k, v in dict(dyn_kind=0, order=20, mu=1.0, rhofac=orc.lib().orc_rhofac(20), delta_t=0.23 * Cn, ct=0.23, nchunks=Cn, reentry_c0=0.0).items():
+        setattr(cfg, k, v)
+    d_state = ctx.array(pop)
+
+    def outputs():
+        return dict(nsub=ctx.empty(n, np.uint32), status=ctx.empty(n, np.int32), ev_idx=ctx.empty(n, np.uint32), ev_time=ctx.empty(n, np.float64),
+                    nf=ctx.empty(n, np.float64), final=ctx.empty((n, 6), np.float64), lbs=ctx.empty((Cn, n, 4), np.float32),
+                    ubs=ctx.empty((Cn, n, 4), np.float32), recs=ctx.empty((Cn, n, 16), np.float32))
+
+    def args(d):
+        return (h, C.byref(cfg), n, d_state.ptr, d["nsub"].ptr, d["status"].ptr, d["ev_idx"].ptr, d["ev_time"].ptr, d["nf"].ptr, d["final"].ptr, d["lbs"].ptr, d["ubs"].ptr, d["recs"].ptr)
+
+    # Boxes fused into the integration (what the oracle-parity tests pin) against the boxes that
+    # k_chunk_boxes computes from the rows of a pass that writes them: the same bits at full size.
+    f = outputs()
+    chk(L.csc_propagate(*args(f)))
+    nsub = f["nsub"].download()
+    cap = int(nsub.max()) + 1
+    assert 2 <= cap <= 8
+    r = outputs()
+    d_row, d_xyz = ctx.empty(n, np.uint64), ctx.empty((n * cap, 64), np.float64)
+    d_vr, d_tco = ctx.empty((n * cap, 84), np.float64), ctx.empty((n * cap, 2), np.float64)
+    chk(L.csc_propagate_rows(*args(r), cap, d_row.ptr, d_xyz.ptr, d_vr.ptr, d_tco.ptr))
+    summ = _capi.PropSummary()
+    chk(L.csc_propagate_summary(h, n, r["nsub"].ptr, r["status"].ptr, r["ev_idx"].ptr, r["ev_time"].ptr, r["nf"].ptr, C.byref(summ)))
+    assert summ.n_nf == 0 and summ.n_ste == 0 and summ.flags == 0 and summ.total_substeps == int(nsub.sum())
+    lbs, ubs = r["lbs"].download(), r["ubs"].download()
+    for k in ("nsub", "status", "final"):
+        assert np.array_equal(f[k].download(), r[k].download()), k
+    assert np.array_equal(f["lbs"].download().view(np.uint32), lbs.view(np.uint32)) and np.array_equal(f["ubs"].download().view(np.uint32), ubs.view(np.uint32))
+    assert np.array_equal(f["recs"].download().view(np.uint32), r["recs"].download().view(np.uint32))
+    assert np.all(np.isfinite(lbs)) and np.all(lbs <= ubs)
+    # chunk 0 contains the initial position, chunk 7 the final one, consecutive chunks overlap
+    fin = r["final"].download()
+    p0, p1 = pop[:, :3].astype(np.float32), fin[:, :3].astype(np.float32)
+    assert np.all(lbs[0, :, :3] <= p0) and np.all(p0 <= ubs[0, :, :3]) and np.all(lbs[7, :, :3] <= p1) and np.all(p1 <= ubs[7, :, :3])
+    assert np.all(lbs[1:] <= ubs[:-1]) and np.all(lbs[:-1] <= ubs[1:])
+    del f
+
+    d_glb, d_gub = ctx.empty((Cn, 4), np.float32), ctx.empty((Cn, 4), np.float32)
+    chk(L.csc_global_aabb(h, n, Cn, r["lbs"].ptr, r["ubs"].ptr, d_glb.ptr, d_gub.ptr))
+    assert np.array_equal(d_glb.download(), lbs.min(axis=1)) and np.array_equal(d_gub.download(), ubs.max(axis=1))
+    d_codes = ctx.empty((Cn, n), np.uint64)
+    chk(L.csc_morton_encode(h, n, Cn, r["lbs"].ptr, r["ubs"].ptr, d_glb.ptr, d_gub.ptr, d_codes.ptr))
+    chk(L.csc_check_flags(h))
+    d_vidx, d_sc = ctx.empty((Cn, n), np.uint32), ctx.empty((Cn, n), np.uint64)
+    d_slb, d_sub, d_srec = ctx.empty((Cn, n, 4), np.float32), ctx.empty((Cn, n, 4), np.float32), ctx.empty((Cn, n, 16), np.float32)
+    chk(L.csc_sort_gather(h, n, Cn, d_codes.ptr, r["lbs"].ptr, r["ubs"].ptr, d_vidx.ptr, d_sc.ptr, d_slb.ptr, d_sub.ptr, r["recs"].ptr, d_srec.ptr))
+    codes, vidx, sc = d_codes.download(), d_vidx.download(), d_sc.download()
+    slb, sub, recs, srec = d_slb.download(), d_sub.download(), r["recs"].download(), d_srec.download()
+    for c in range(Cn):
+        assert np.all(sc[c, 1:] >= sc[c, :-1])
+        assert np.array_equal(np.bincount(vidx[c], minlength=n), np.ones(n, dtype=np.int64)), "a permutation"
+        assert np.array_equal(sc[c], codes[c][vidx[c]])
+        ties = sc[c, 1:] == sc[c, :-1]
+        assert np.all(vidx[c, 1:][ties] > vidx[c, :-1][ties]), "stable: ties in original order"
+        assert np.array_equal(slb[c], lbs[c][vidx[c]]) and np.array_equal(sub[c], ubs[c][vidx[c]])
+        assert np.array_equal(srec[c].view(np.uint32), recs[c][vidx[c]].view(np.uint32))
+    assert len({codes[c].tobytes() for c in range(Cn)}) == Cn, "every chunk has its own codes"
+
+    chk(L.csc_bvh_build(h, n, Cn, d_sc.ptr, d_slb.ptr, d_sub.ptr))
+    act = np.ones(n, dtype=np.uint8)
+    d_act = ctx.array(act)
+    npairs = C.c_uint64()
+    chk(L.csc_broad_phase(h, n, Cn, d_slb.ptr, d_sub.ptr, d_vidx.ptr, d_act.ptr, C.byref(npairs)))
+    assert L.csc_broad_phase_node_pairs(h) > 0 and L.csc_broad_phase_tiles(h) > 0, "dual traversal ending in tiles"
+    rng = np.random.default_rng(3)
+    tot = 0
+    for c in range(Cn):
+        cnt = C.c_uint64()
+        got = np.empty((npairs.value // Cn * 2, 2), dtype=np.uint32)
+        chk(L.csc_broad_phase_get(h, c, got.ctypes.data_as(C.c_void_p), len(got), C.byref(cnt)))
+        assert cnt.value <= len(got)
+        got = got[: cnt.value]
+        tot += cnt.value
+        assert cnt.value > 20 * n and np.all(got[:, 0] < got[:, 1])
+        if c in (0, 5):
+            key = np.sort(got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1].astype(np.uint64))
+            assert np.all(key[1:] != key[:-1]), "no duplicates"
+        # brute force for a sample of objects that do not share their Morton code (those are tested against the leaf's box)
+        multi = np.zeros(n, dtype=bool)
+        t = np.flatnonzero(sc[c, 1:] == sc[c, :-1])
+        multi[vidx[c][t]] = True
+        multi[vidx[c][t + 1]] = True
+        for p in rng.choice(np.flatnonzero(~multi), 12, replace=False):
+            ov = np.all((ubs[c] >= lbs[c][p]) & (lbs[c] <= ubs[c][p]), axis=1) & ~multi
+            ov[p] = False
+            mine = np.concatenate([got[got[:, 0] == p, 1], got[got[:, 1] == p, 0]])
+            assert np.array_equal(np.sort(mine), np.flatnonzero(ov)), "pairs of a sampled object = brute force"
+    assert tot == npairs.value
+    del r, d_xyz, d_vr, d_tco
+    ctx.close()
+
+    # Whole supersteps: deterministic, the per-particle walks find as many pairs, Kepler invariants,
+    # and the states of a sample agree with the oracle run on that sample alone.
+    def run(mode, steps):
+        if mode:
+            monkeypatch.setenv("CASCADE_BP_MODE", mode)
+        else:
+            monkeypatch.delenv("CASCADE_BP_MODE", raising=False)
+        s = sim(pop.copy(), 0.23, n_par_ct=Cn)
+        s.host_sync = False
+        pairs = []
+        for _ in range(steps):
+            assert s.step().name == "success"
+            pairs.append(s.last_bp_pairs)
+        s.download_state()
+        return s, pairs
+
+    a, pa = run(None, 3)
+    assert pa[0] == npairs.value, "step() and the stage calls find the same pairs"
+    b, pb = run(None, 3)
+    assert pa == pb and np.array_equal(a.state, b.state), "deterministic"
+    w, pw = run("walk", 1)
+    assert pw[0] == pa[0], "dual traversal + tiles and per-particle walks find the same number of pairs"
+    rv, vv = pop[:, :3], pop[:, 3:6]
+    r1, v1 = a.state[:, :3], a.state[:, 3:6]
+    e0 = 0.5 * np.sum(vv * vv, axis=1) - 1.0 / np.linalg.norm(rv, axis=1)
+    e1 = 0.5 * np.sum(v1 * v1, axis=1) - 1.0 / np.linalg.norm(r1, axis=1)
+    assert np.max(np.abs(e1 - e0)) < 1e-13 and np.max(np.abs(np.cross(r1, v1) - np.cross(rv, vv))) < 1e-13
+    assert abs(a.time - 3 * 8 * 0.23) < 1e-14
+    idx = np.sort(np.random.default_rng(1).choice(N, 3000, replace=False))
+    o = orc.Sim(pop[idx].copy(), 0.23, n_par_ct=Cn)
+    for _ in range(3):
+        assert o.step() == "success"
+    assert np.all(np.abs(a.state[idx] - o.state) <= 1e-9 * np.maximum(1.0, np.abs(o.state)))
