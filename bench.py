@@ -453,8 +453,8 @@ def launch_ranks(n):
     lines = [l for l in (out0 or "").splitlines() if l.strip()]
     if rc == 0 and not any(l.startswith("{") for l in lines):
         rc = 1
-    for l in lines:
-        print(l)
+    for l in lines:  # (the JSON line on stdout, anything else a library printed there on stderr)
+        print(l, file=sys.stdout if l.startswith("{") else sys.stderr)
     if rc != 0:
         print("bench.py: a rank failed (exit code %d)" % rc, file=sys.stderr)
     return rc

@@ -123,6 +123,7 @@ SYMBOLS = {
     "csc_bvh_build": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "csc_bvh_export": (_i32, [_vp, _u32, _vp, _u64, C.POINTER(_u64)]),
     "csc_broad_phase": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "csc_broad_phase_filtered": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.c_double, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "csc_set_shard": (_i32, [_vp, _u32, _u32]),
     "csc_set_chunk_map": (_i32, [_vp, _u32, _u32]),
     "csc_broad_phase_stats": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

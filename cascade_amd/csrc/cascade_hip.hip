@@ -93,6 +93,7 @@ struct csc_ctx {
     // dual traversal (k_bp_dual.hpp): flat pair lists of the last broad phase, capacities that
     // follow the last superstep
     bool bp_flat = false;
+    bool bp_fused = false; // the last broad phase filtered its pairs on chip and kept no pair list
     const unsigned long long *bp_flat_pairs = nullptr;
     uint32_t bp_flat_cap = 0;
     uint32_t bp_flat_cnt[csc::DT_SHARDS] = {};
@@ -948,13 +949,15 @@ namespace
 
 constexpr unsigned XFER_CHUNKS = 16, XFER_THREADS = 8;
 
-// 128-bit position-dependent checksum of 8-byte words. Every word goes through a full avalanche
-// (two different multiply / xor-shift finalisers of the word combined with its position) BEFORE it
-// is added to the two 64-bit lanes, so a structured edit -- an even number of sign flips, +d / -d on
-// two words, two rows swapped -- changes each lane by a sum of pseudo-random 64-bit terms that
-// cancels with probability 2^-64 per lane (2^-128 for both). The sums are order-independent, so
-// the chunks of a transfer combine by addition. (Round 2 added (w ^ k) * odd without the avalanche:
-// linear mod 2^64, blind to any even number of bit-63 flips.)
+// 128-bit position-dependent checksum of 8-byte words. The words are taken in pairs (2j, 2j + 1);
+// each pair, xored with two position-dependent keys, goes through a full 64 x 64 -> 128 bit
+// multiplication whose halves are folded together (the "mum" mixer of wyhash), once per lane with
+// different keys, BEFORE it is added to the lane. A product is non-linear in every bit of both
+// words, so a structured edit -- an even number of sign flips, +d / -d on two words, two rows
+// swapped -- changes each lane by a sum of pseudo-random 64-bit terms that cancels with probability
+// 2^-64 per lane (2^-128 for both). The sums are order-independent, so pieces that start at even
+// word indices combine by addition. (Round 2 added (w ^ k) * odd without any mixing: linear mod
+// 2^64, blind to any even number of bit-63 flips.)
 struct hash128 {
     uint64_t a = 0, b = 0;
     void operator+=(const hash128 &o)
@@ -964,27 +967,25 @@ struct hash128 {
     }
 };
 
+extern "C++" inline uint64_t hash_mum(uint64_t x, uint64_t y)
+{
+    const unsigned __int128 m = static_cast<unsigned __int128>(x) * y;
+    return static_cast<uint64_t>(m) ^ static_cast<uint64_t>(m >> 64);
+}
+
+// first_word must be even; an odd word count pairs the last word with a zero.
 extern "C++" inline hash128 hash_words(const unsigned char *p, size_t first_word, size_t nwords)
 {
     hash128 h;
-    for (size_t i = 0; i < nwords; ++i) {
-        uint64_t w;
-        std::memcpy(&w, p + i * 8u, 8);
-        const uint64_t k = (first_word + i + 1u) * 0x9e3779b97f4a7c15ull;
-        uint64_t x = w ^ k; // murmur3's fmix64
-        x ^= x >> 33;
-        x *= 0xff51afd7ed558ccdull;
-        x ^= x >> 33;
-        x *= 0xc4ceb9fe1a85ec53ull;
-        x ^= x >> 33;
-        uint64_t y = w + (k ^ 0x2545f4914f6cdd1dull); // splitmix64's finaliser, other constants
-        y ^= y >> 30;
-        y *= 0xbf58476d1ce4e5b9ull;
-        y ^= y >> 27;
-        y *= 0x94d049bb133111ebull;
-        y ^= y >> 31;
-        h.a += x;
-        h.b += y;
+    for (size_t i = 0; i < nwords; i += 2u) {
+        uint64_t w0, w1 = 0;
+        std::memcpy(&w0, p + i * 8u, 8);
+        if (i + 1u < nwords) {
+            std::memcpy(&w1, p + (i + 1u) * 8u, 8);
+        }
+        const uint64_t k = (first_word + i + 1u) * 0x9e3779b97f4a7c15ull; // (odd multiples: never 0)
+        h.a += hash_mum(w0 ^ k, w1 ^ (k + 0xa0761d6478bd642full));
+        h.b += hash_mum(w0 ^ ((k >> 7 | k << 57) + 0xe7037ed1a0b428dbull), w1 ^ (~k * 0x8ebc6af09c88c6e3ull));
     }
     return h;
 }
@@ -1022,7 +1023,7 @@ void csc_host_hash(const void *p, size_t bytes, uint64_t out[2])
     const size_t nwords = bytes / 8u;
     const unsigned nt = nwords < (1u << 16) ? 1u : std::max(1u, std::min(XFER_THREADS, std::thread::hardware_concurrency()));
     std::vector<hash128> part(nt);
-    const size_t per = (nwords + nt - 1) / nt;
+    const size_t per = ((nwords + nt - 1) / nt + 1u) & ~static_cast<size_t>(1); // (even: whole pairs)
     auto work = [&](unsigned t) {
         const size_t b = std::min(nwords, t * per), e = std::min(nwords, b + per);
         part[t] = hash_words(static_cast<const unsigned char *>(p) + b * 8u, b, e - b);
@@ -1043,7 +1044,7 @@ void csc_host_hash(const void *p, size_t bytes, uint64_t out[2])
     if (bytes % 8u != 0u) {
         unsigned char tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         std::memcpy(tail, static_cast<const unsigned char *>(p) + nwords * 8u, bytes % 8u);
-        h += hash_words(tail, nwords, 1);
+        h += hash_words(tail, (nwords + 2u) & ~static_cast<size_t>(1), 1);
     }
     out[0] = h.a;
     out[1] = h.b;
@@ -1068,7 +1069,7 @@ int csc_upload(csc_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_
     }
     // The staging mirror may still be the source of an earlier upload's DMA.
     CSC_HIP(hipStreamSynchronize(ctx->stream));
-    const size_t nwords = bytes / 8u, per = (nwords + XFER_CHUNKS - 1) / XFER_CHUNKS;
+    const size_t nwords = bytes / 8u, per = ((nwords + XFER_CHUNKS - 1) / XFER_CHUNKS + 1u) & ~static_cast<size_t>(1); // (even: whole pairs)
     const unsigned nt = std::max(1u, std::min(XFER_THREADS, std::thread::hardware_concurrency()));
     std::vector<hash128> part(XFER_CHUNKS);
     std::vector<hipError_t> err(nt, hipSuccess);
@@ -1137,7 +1138,7 @@ int csc_download(csc_ctx *ctx, void *dst, const void *d_src, size_t bytes, uint6
     // Everything queued on the context's stream has to be done before the copies start.
     CSC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     CSC_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev0, 0));
-    const size_t nwords = bytes / 8u, per = (nwords + XFER_CHUNKS - 1) / XFER_CHUNKS;
+    const size_t nwords = bytes / 8u, per = ((nwords + XFER_CHUNKS - 1) / XFER_CHUNKS + 1u) & ~static_cast<size_t>(1); // (even: whole pairs)
     for (unsigned c = 0; c < XFER_CHUNKS; ++c) {
         const size_t b = std::min(nwords, c * per), e = std::min(nwords, b + per);
         if (b < e) {
@@ -1939,23 +1940,32 @@ int csc_set_shard(csc_ctx *ctx, uint32_t rank, uint32_t nranks)
 // Dual traversal (k_bp_dual.hpp): one launch per level of the pair tree, the frontier sizes stay
 // on the device; the host looks at them every few levels to stop.
 static_assert(csc::NP_FLAT_SHARDS == csc::DT_SHARDS, "flat pair lists");
+// csc_broad_phase_filtered: the tiles' hits go through the narrow phase's exclusion test on chip.
+struct bp_fuse {
+    const float *srt_recs;
+    double conj_thresh;
+};
 static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                             const uint32_t *d_vidx, const uint8_t *d_active, const csc::tnode *d_tn, const uint8_t *d_sact,
                             const uint32_t *d_sinfo, const uint32_t *d_sleaf, const uint32_t *d_multi, uint32_t tile_max,
-                            uint64_t *n_pairs)
+                            uint64_t *n_pairs, const bp_fuse *fuse = nullptr)
 {
     using namespace csc;
     const size_t ctr_per_level = static_cast<size_t>(DT_SHARDS) * DT_CTR_STRIDE;
-    CSC_BUF(d_cnt, uint32_t, "dt_counters", ctr_per_level * (DT_MAX_LEVELS + 3));
+    CSC_BUF(d_cnt, uint32_t, "dt_counters", ctr_per_level * (DT_MAX_LEVELS + 5));
     uint32_t *d_pair_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 1);
     uint32_t *d_tile_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 2);
+    uint32_t *d_fuse_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 3);
+    uint32_t *d_cand_cnt = d_cnt + ctr_per_level * (DT_MAX_LEVELS + 4);
+    // (fused: the candidates that survive the on-chip exclusion test; what the last superstep needed)
+    uint32_t cand_cap = fuse ? static_cast<uint32_t>(std::max<size_t>(ctx->bufs["np_cand"].cap / sizeof(uint4), 262144)) : 0u;
     // Tiles: about 6 per particle at 1M objects with tiles of 16.
     uint32_t tile_cap = tile_max ? std::max<uint32_t>({ctx->dt_tile_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u}) : 1u;
     // First guesses: 4 frontier items and 8 pairs per particle and chunk; afterwards what the last
     // superstep needed (populations change slowly), and an overflow redoes the traversal.
     uint32_t fr_cap = std::max<uint32_t>({ctx->dt_fr_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 4u, 4096u});
     uint32_t pair_cap = std::max<uint32_t>({ctx->dt_pair_cap, cdiv(static_cast<uint64_t>(n) * nchunks, DT_SHARDS) * 8u, 4096u});
-    std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 3));
+    std::vector<uint32_t> hc(ctr_per_level * (DT_MAX_LEVELS + 5));
     // Workgroups per shard (each strides over the DT_BLOCK-item tiles of its shard): 512 of 128
     // threads, i.e. 16384 workgroups in all, measured best at 1M objects (per traversal: 1.65 ms
     // with 64 x 256 threads, 1.47 with 256 x 256, 1.42 with 512 x 128, 1.45 with 1024 x 128, 1.47
@@ -1971,6 +1981,11 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         CSC_BUF(d_fb, unsigned long long, "dt_frontier_b", static_cast<size_t>(fr_cap) * DT_SHARDS);
         CSC_BUF(d_pairs, unsigned long long, "dt_pairs", static_cast<size_t>(pair_cap) * DT_SHARDS);
         CSC_BUF(d_tiles, unsigned long long, "dt_tiles", static_cast<size_t>(tile_cap) * DT_SHARDS);
+        uint4 *d_cand = nullptr;
+        if (fuse) {
+            CSC_BUF(d_cand_, uint4, "np_cand", cand_cap);
+            d_cand = d_cand_;
+        }
         CSC_HIP(hipMemsetAsync(d_cnt, 0, hc.size() * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_bp_dual_init, dim3(cdiv(nchunks, 64)), dim3(64), 0, ctx->stream, nchunks, ctx->bvh.nn_max, ctx->bvh.nleft,
                            d_fa, d_cnt);
@@ -2001,6 +2016,14 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         q.sinfo = d_sinfo;
         q.sleaf = d_sleaf;
         q.multi_flag = d_multi;
+        if (fuse) {
+            q.srecs = reinterpret_cast<const float4 *>(fuse->srt_recs);
+            q.thr_extra = static_cast<float>(fuse->conj_thresh);
+            q.cand = d_cand;
+            q.cand_cnt = d_cand_cnt;
+            q.cand_cap = cand_cap;
+            q.fuse_cnt = d_fuse_cnt;
+        }
         int level = 0;
         bool done = false;
         // Tiles are handed to k_bp_tiles as soon as the levels the last traversal needed (+ 1) have
@@ -2016,7 +2039,11 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
             }
             // Workgroups stride over the tile batches of their shard: 8 per CU fill the chip.
             const unsigned tg = static_cast<uint64_t>(n) * nchunks >= 200000u ? 2048u : 256u;
-            if (tile_max <= 8u) {
+            if (fuse && tile_max <= 8u) {
+                KT("k_bp_tiles", hipLaunchKernelGGL((k_bp_tiles<8, true>), dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            } else if (fuse) {
+                KT("k_bp_tiles", hipLaunchKernelGGL((k_bp_tiles<16, true>), dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+            } else if (tile_max <= 8u) {
                 KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
             } else {
                 KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<16>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
@@ -2054,7 +2081,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
             }
             // Everything the host wants to know, in one go.
             CSC_HIP(hipMemcpyAsync(hc.data(), d_cnt, ctr_per_level * (level + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 2 * ctr_per_level * sizeof(uint32_t),
+            CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 4 * ctr_per_level * sizeof(uint32_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
             CSC_HIP(hipMemcpyAsync(flags_h, ctx->d_flags, sizeof(flags_h), hipMemcpyDeviceToHost, ctx->stream));
             CSC_HIP(hipStreamSynchronize(ctx->stream));
@@ -2083,7 +2110,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
             if (more) {
                 launch_tiles();
                 CSC_LAUNCH_CHECK();
-                CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 2 * ctr_per_level * sizeof(uint32_t),
+                CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 1), d_pair_cnt, 4 * ctr_per_level * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, ctx->stream));
                 CSC_HIP(hipStreamSynchronize(ctx->stream));
             }
@@ -2130,7 +2157,53 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
         }
         ctx->dt_fr_cap = std::max(ctx->dt_fr_cap, max_fr + max_fr / 4u + 1024u);
         ctx->dt_pair_cap = std::max(ctx->dt_pair_cap, max_pr + max_pr / 4u + 1024u);
+        uint32_t ncand = 0;
+        if (fuse && max_fr <= fr_cap && max_pr <= pair_cap && max_tl <= tile_cap) {
+            // The pairs that the traversal wrote itself (members of oversized multi-particle leaves:
+            // rare, usually none) take the stored-list version of the same test, into the same list.
+            if (total != 0u) {
+                np_params f{};
+                f.n = n;
+                f.nchunks = nchunks;
+                f.flat_pairs = d_pairs;
+                f.flat_cap = pair_cap;
+                uint32_t flat_tiles = 0;
+                for (int s = 0; s < NP_FLAT_SHARDS; ++s) {
+                    f.flat_cnt[s] = ctx->bp_flat_cnt[s];
+                    f.flat_tile_off[s] = flat_tiles;
+                    flat_tiles += cdiv(ctx->bp_flat_cnt[s], NP_FLAT_TILE);
+                }
+                f.flat_tile_off[NP_FLAT_SHARDS] = flat_tiles;
+                f.vidx = d_vidx;
+                f.srt_recs = reinterpret_cast<const float4 *>(fuse->srt_recs);
+                f.thr_extra = fuse->conj_thresh;
+                f.cand = d_cand;
+                f.cand_cap = cand_cap;
+                f.counters = d_cand_cnt - 5; // (the kernel touches counters[5] only)
+                KT("k_np_prefilter", hipLaunchKernelGGL((k_np_prefilter_flat<true>), dim3(std::min<uint32_t>(flat_tiles, 2048u)),
+                                                         dim3(NP_FLAT_BLOCK), 0, ctx->stream, f));
+                CSC_LAUNCH_CHECK();
+                CSC_HIP(hipMemcpyAsync(hc.data() + ctr_per_level * (DT_MAX_LEVELS + 4), d_cand_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+                CSC_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            ncand = hc[ctr_per_level * (DT_MAX_LEVELS + 4)];
+            for (int s = 0; s < DT_SHARDS; ++s) {
+                total += hc[ctr_per_level * (DT_MAX_LEVELS + 3) + static_cast<size_t>(s) * DT_CTR_STRIDE];
+            }
+        }
+        if (fuse && ncand > cand_cap) {
+            cand_cap = ncand + ncand / 4u + 16u; // (counted in full: one more pass is enough)
+            continue;
+        }
         if (max_fr <= fr_cap && max_pr <= pair_cap && max_tl <= tile_cap) {
+            ctx->bp_fused = fuse != nullptr;
+            if (fuse) {
+                ctx->np_cand_list = d_cand;
+                ctx->np_cand_count = ncand;
+                ctx->np_candidates = ncand;
+                ctx->np_cand_valid = true;
+            }
             ctx->bp_flat = true;
             ctx->bp_flat_pairs = d_pairs;
             ctx->bp_flat_cap = pair_cap;
@@ -2159,9 +2232,10 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
     return CSC_ERR_OVERFLOW;
 }
 
-int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
-                    const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs)
+static int broad_phase_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                            const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs, const bp_fuse *fuse)
 {
+    ctx->bp_fused = false;
     if (n != ctx->bvh_n || nchunks > ctx->bvh_chunks) {
         return ctx->invalid("broad phase does not match the last BVH build");
     }
@@ -2201,7 +2275,8 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     ctx->bp_node_pairs = 0;
     ctx->bp_tiles = 0;
     if (dual) {
-        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, d_multi, tile_max, n_pairs);
+        return broad_phase_dual(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, d_tn, d_sact, d_sinfo, d_sleaf, d_multi, tile_max, n_pairs,
+                                tile_max != 0u ? fuse : nullptr);
     }
     csc::bp_params q{};
     q.n = n;
@@ -2294,6 +2369,33 @@ int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_s
     return CSC_OK;
 }
 
+int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                    const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs)
+{
+    return broad_phase_impl(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, n_pairs, nullptr);
+}
+
+int csc_broad_phase_filtered(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                             const uint32_t *d_vidx, const uint8_t *d_active, double conj_thresh, const float *d_srt_recs,
+                             uint64_t *n_pairs, uint64_t *n_cand)
+{
+    if (d_srt_recs == nullptr) {
+        return ctx->invalid("csc_broad_phase_filtered needs the sorted trajectory records");
+    }
+    const bp_fuse fuse{d_srt_recs, conj_thresh};
+    if (const int rc = broad_phase_impl(ctx, n, nchunks, d_srt_lbs, d_srt_ubs, d_vidx, d_active, n_pairs, &fuse)) {
+        return rc;
+    }
+    if (!ctx->bp_fused) {
+        // (no tiles in this configuration: the stored pair list, then the same test over it)
+        return csc_narrow_phase_prefilter(ctx, n, nchunks, conj_thresh, d_srt_recs, n_cand);
+    }
+    if (n_cand) {
+        *n_cand = ctx->np_cand_count;
+    }
+    return CSC_OK;
+}
+
 #ifdef CSC_BP_GROUP_STATS
 int csc_debug_gstats(csc_ctx *ctx, uint32_t *out, uint32_t nlists)
 {
@@ -2336,6 +2438,9 @@ int csc_broad_phase_get(csc_ctx *ctx, uint32_t chunk, uint32_t *pairs, uint64_t 
 {
     if (chunk >= ctx->bp_chunks) {
         return ctx->invalid("invalid chunk index");
+    }
+    if (ctx->bp_fused) {
+        return ctx->invalid("the last broad phase (csc_broad_phase_filtered) kept no pair list");
     }
     if (ctx->bp_flat) {
         std::vector<uint32_t> vx(ctx->bp_n);
@@ -2699,7 +2804,7 @@ int csc_narrow_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, doub
                      const double *d_tcs_vr, const double *d_tcoords, const float *d_srt_recs, uint64_t *n_coll,
                      uint64_t *n_conj, uint32_t *warn_flags)
 {
-    if (n != ctx->bp_n || nchunks > ctx->bp_chunks) {
+    if (n != ctx->bp_n || nchunks > ctx->bp_chunks || ctx->bp_fused) {
         return ctx->invalid("narrow phase does not match the last broad phase");
     }
     // After a terminal-event shrink the kernels skip the pairs of the dropped chunks.
@@ -2750,7 +2855,7 @@ int csc_narrow_phase_pairs(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct
 int csc_narrow_phase_prefilter(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double conj_thresh, const float *d_srt_recs,
                                uint64_t *n_cand)
 {
-    if (n != ctx->bp_n || nchunks > ctx->bp_chunks) {
+    if (n != ctx->bp_n || nchunks > ctx->bp_chunks || ctx->bp_fused) {
         return ctx->invalid("narrow phase does not match the last broad phase");
     }
     if (d_srt_recs == nullptr) {

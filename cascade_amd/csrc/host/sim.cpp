@@ -1515,7 +1515,14 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     } else {
         d.chk(csc_set_shard(ctx, d.shard_rank, d.shard_n));
     }
-    if (have_chunks) {
+    // With the pre-filter on, the box-overlap pairs are counted and filtered inside the tile kernel
+    // of the traversal and only the candidates of the polynomial test are stored (csc_broad_phase_filtered).
+    static const bool fuse_env = !(std::getenv("CASCADE_BP_FUSE") && std::atoi(std::getenv("CASCADE_BP_FUSE")) == 0);
+    const bool fused = have_chunks && d.np_prefilter && d_srecs != nullptr && fuse_env;
+    if (fused) {
+        std::uint64_t ncand = 0;
+        d.chk(csc_broad_phase_filtered(ctx, n, cl, d_slbs, d_subs, d_vidx, d_active, m_conj_thresh, d_srecs, &npairs, &ncand));
+    } else if (have_chunks) {
         d.chk(csc_broad_phase(ctx, n, cl, d_slbs, d_subs, d_vidx, d_active, &npairs));
     }
     if (tracing) {
@@ -1551,8 +1558,10 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     } else if (sparse) {
         std::uint64_t ncand = 0, nrows = 0;
         std::uint32_t nlist = 0;
-        d.chk(csc_narrow_phase_prefilter(ctx, n, cl, m_conj_thresh, d_srecs, &ncand));
-        np_attempts += csc_narrow_phase_attempts(ctx) - 1u;
+        if (!fused) {
+            d.chk(csc_narrow_phase_prefilter(ctx, n, cl, m_conj_thresh, d_srecs, &ncand));
+            np_attempts += csc_narrow_phase_attempts(ctx) - 1u;
+        }
         auto *d_list = d.buf<std::uint32_t>("cand_objects", n);
         d.chk(csc_candidate_objects(ctx, n, d_nsub, d_list, &nlist, nullptr));
         // (an upper bound is enough: the listed particles times the largest substep count, and
@@ -1578,8 +1587,13 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         } else {
             d.rows_full = true;
         }
-        d.chk(csc_narrow_phase(ctx, n, cl, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
-                               d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
+        if (fused) {
+            d.chk(csc_narrow_phase_finish(ctx, n, cl, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state,
+                                          d_active, d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, &ncoll, &nconj, &warn));
+        } else {
+            d.chk(csc_narrow_phase(ctx, n, cl, m_ct, delta_t, d.time.hi, d.time.lo, m_conj_thresh, d.order, d_state, d_active,
+                                   d_tc_row, d_nsub, d_txyz, d_tvr, d_tco, d_srecs, &ncoll, &nconj, &warn));
+        }
     }
     if (!rows_done && have_chunks) {
         // A second integration pass wrote the rows: it must have repeated the substep counts of the

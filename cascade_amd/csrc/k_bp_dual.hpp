@@ -35,6 +35,7 @@
 
 #include <type_traits>
 #include "k_bvh.hpp"
+#include "k_chord.hpp"
 
 namespace csc
 {
@@ -74,6 +75,16 @@ struct dual_params {
     std::uint32_t tile_begin[DT_SHARDS]; // k_bp_tiles starts here in every shard's list (a second launch: the tiles added since)
     const std::uint32_t *sinfo;   // [C][n] orig | act << 24 | multi-leaf member << 26 (k_bvh_pack)
     const std::uint32_t *sleaf;   // [C][n] leaf of a multi-leaf member
+    // k_bp_tiles<.., FUSE>: the hits of the tiles are not stored. They are counted (fuse_cnt, per
+    // shard) and put through the geometric exclusion test of the narrow phase (k_chord.hpp) while
+    // they sit in the wave's buffer; only the survivors leave the chip, as narrow-phase candidates
+    // {orig_i < orig_j, chunk, 0}.
+    const float4 *srecs;          // [C][n][4] sampled-trajectory records in sorted order
+    float thr_extra;              // conjunction threshold (0: collisions only)
+    uint4 *cand;                  // [cand_cap]
+    std::uint32_t *cand_cnt;      // one counter
+    std::uint32_t cand_cap;
+    std::uint32_t *fuse_cnt;      // [DT_SHARDS * DT_CTR_STRIDE] box-overlap pairs found by the tiles
 };
 
 // DT_FROZEN: an internal node that is small enough for a tile (<= tile_max particles) paired
@@ -509,7 +520,7 @@ CSC_DEV void dt_tile_decode(unsigned long long rec, bool valid, dt_tile_in &t)
     t.c = valid ? static_cast<std::uint32_t>(rec >> 56) : 0u;
 }
 
-template <int TL>
+template <int TL, bool FUSE = false>
 __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_params q)
 {
     constexpr int TPW = 64 / TL;
@@ -550,6 +561,59 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
     wave_sync();
     // The wave's pair buffer -> the pair list of the shard: one atomic, coalesced stores.
     auto flush = [&](std::uint32_t fill) {
+        if constexpr (FUSE) {
+            // Count the pairs, test them (64 at a time, every lane busy: the records of a tile's
+            // particles are neighbours in the sorted array, so the two 64-byte gathers per pair hit
+            // the lines that the other pairs of the tile fetch), append the survivors.
+            if (lane == 0) {
+                atomicAdd(q.fuse_cnt + shard * DT_CTR_STRIDE, fill);
+                *fillp = 0u;
+            }
+            // (two groups of 64 pairs per trip: the record gathers of both are in flight together)
+            for (std::uint32_t k0 = 0; k0 < fill; k0 += 128u) {
+                bool keep[2];
+                std::uint32_t pa[2], pb[2], c[2];
+                float4 ra[2][4], rb[2][4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const std::uint32_t k = k0 + 64u * g + lane;
+                    keep[g] = k < fill;
+                    const unsigned long long rec = buf[keep[g] ? k : k0];
+                    pa[g] = static_cast<std::uint32_t>(rec) & 0xfffffffu;
+                    pb[g] = static_cast<std::uint32_t>(rec >> 28) & 0xfffffffu;
+                    c[g] = static_cast<std::uint32_t>(rec >> 56);
+                    const float4 *qa = q.srecs + (static_cast<std::size_t>(c[g]) * q.n + pa[g]) * 4u;
+                    const float4 *qb = q.srecs + (static_cast<std::size_t>(c[g]) * q.n + pb[g]) * 4u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ra[g][e] = qa[e];
+                        rb[g][e] = qb[e];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    keep[g] = keep[g] && chord_keep_recs(ra[g], rb[g], q.thr_extra);
+                    const unsigned long long km = __ballot(keep[g]);
+                    if (km != 0ull) {
+                        std::uint32_t base = 0;
+                        if (lane == 0) {
+                            base = atomicAdd(q.cand_cnt, static_cast<std::uint32_t>(__popcll(km)));
+                        }
+                        base = __shfl(base, 0);
+                        if (keep[g]) {
+                            const std::uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(static_cast<std::uint32_t>(km >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<std::uint32_t>(km), 0u));
+                            if (slot < q.cand_cap) {
+                                const std::size_t co = static_cast<std::size_t>(c[g]) * q.n;
+                                const std::uint32_t oa = q.vidx[co + pa[g]], ob = q.vidx[co + pb[g]];
+                                q.cand[slot] = make_uint4(oa < ob ? oa : ob, oa < ob ? ob : oa, c[g], 0u);
+                            }
+                        }
+                    }
+                }
+            }
+            wave_sync();
+            return;
+        }
         std::uint32_t base = 0;
         if (lane == 0) {
             base = atomicAdd(pair_cnt, fill);

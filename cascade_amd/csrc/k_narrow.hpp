@@ -24,6 +24,7 @@
 
 #include "dev_math.hpp"
 #include "k_bvh.hpp"
+#include "k_chord.hpp"
 #include "k_propagate.hpp"
 
 namespace csc
@@ -550,44 +551,10 @@ CSC_DEV double np_rsum2(const np_params &q, std::uint32_t pi, std::uint32_t pj)
 // (used to check that the filter does not change any result).
 // The geometric exclusion test for the particles at sorted positions pa, pb of the chunk whose
 // arrays start at offset co. Returns false when the pair can be dropped.
-// The test proper: the sample differences d_s = a_s - b_s, s = 0..4, and the two radii.
-CSC_DEV bool np_prefilter_core(const float (&dx)[5], const float (&dy)[5], const float (&dz)[5], float thr_extra, float deva,
-                               float devb)
-{
-    const float thr = (thr_extra + deva + devb) * 1.000002f;
-    const float thr2 = thr * thr * 1.000002f;
-    bool keep = !(thr2 < __builtin_huge_valf()); // invalid record (dev = +inf) or overflow: never excluded
-#pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) {
-        // min over u in [0, 1] of |d_s + u (d_{s+1} - d_s)|^2
-        const float ex = dx[sidx + 1] - dx[sidx], ey = dy[sidx + 1] - dy[sidx], ez = dz[sidx + 1] - dz[sidx];
-        // (explicit fused multiply-adds: the library is built with -ffp-contract=off for the FP64 stages)
-        const float ee = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
-        const float de = fmaf(dx[sidx], ex, fmaf(dy[sidx], ey, dz[sidx] * ez));
-        // (v_rcp_f32, 1 ulp, instead of the 10-instruction IEEE division: at the minimiser the
-        // distance is stationary in u, so an error of 3e-7 in u changes m2 by ~1e-13 |e|^2)
-        float u = ee > 0.f ? -de * __builtin_amdgcn_rcpf(ee) : 0.f;
-        u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
-        const float mx = fmaf(u, ex, dx[sidx]), my = fmaf(u, ey, dy[sidx]), mz = fmaf(u, ez, dz[sidx]);
-        const float m2 = fmaf(mx, mx, fmaf(my, my, mz * mz));
-        // Any u in [0, 1] gives an upper bound of the true minimum only if it IS the minimiser;
-        // rounding of u moves the point along the segment by ~1e-7 |e|, which the margin in dev
-        // and the factor on thr absorb. NaNs compare false: the pair is kept.
-        keep = keep || !(m2 > thr2);
-    }
-    return keep;
-}
-
+// (np_prefilter_core, chord_keep: k_chord.hpp -- shared with the tile kernel of the broad phase)
 CSC_DEV bool np_prefilter_keep(const np_params &q, std::size_t co, std::uint32_t pa, std::uint32_t pb)
 {
-    const float4 *ra = q.srt_recs + (co + pa) * 4u, *rb = q.srt_recs + (co + pb) * 4u;
-    const float4 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
-    const float4 b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
-    // Sample differences d_s = a_s - b_s, s = 0..4 (x, y, z).
-    const float dx[5] = {a0.x - b0.x, a0.w - b0.w, a1.z - b1.z, a2.y - b2.y, a3.x - b3.x};
-    const float dy[5] = {a0.y - b0.y, a1.x - b1.x, a1.w - b1.w, a2.z - b2.z, a3.y - b3.y};
-    const float dz[5] = {a0.z - b0.z, a1.y - b1.y, a2.x - b2.x, a2.w - b2.w, a3.z - b3.z};
-    return np_prefilter_core(dx, dy, dz, static_cast<float>(q.thr_extra), a3.w, b3.w);
+    return chord_keep(q.srt_recs, co, pa, pb, static_cast<float>(q.thr_extra));
 }
 
 template <bool FILTER>

@@ -306,6 +306,18 @@ int csc_bvh_export(csc_ctx *ctx, uint32_t chunk, csc_bvh_node *d_nodes, uint64_t
  * Synchronises (the totals are read back); *n_pairs = total over chunks. */
 int csc_broad_phase(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
                     const uint32_t *d_vidx, const uint8_t *d_active, uint64_t *n_pairs);
+/* The same traversal with the narrow phase's geometric exclusion test (csc_narrow_phase_prefilter;
+ * no counterpart in the reference) applied to the hits of every tile while they are on chip: the
+ * box-overlap pairs of src/sim_broad_phase.cpp:149-185 are counted (*n_pairs, the figure behind the
+ * reference's "Average number of AABB collisions per particle per chunk", :211-213) but not stored;
+ * only the pairs that the test cannot exclude leave the chip, as the candidate list that
+ * csc_candidate_objects and csc_narrow_phase_finish take (*n_cand). What sim::step() calls;
+ * csc_broad_phase + csc_broad_phase_get stay the stage that exports the bit-exact pair set. After
+ * this call there is no pair list (csc_broad_phase_get / csc_narrow_phase return an error). d_srt_recs:
+ * the sorted trajectory records of csc_sort_gather. Synchronises. */
+int csc_broad_phase_filtered(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d_srt_lbs, const float *d_srt_ubs,
+                             const uint32_t *d_vidx, const uint8_t *d_active, double conj_thresh, const float *d_srt_recs,
+                             uint64_t *n_pairs, uint64_t *n_cand);
 /* Node pairs expanded by the last csc_broad_phase (the work units of the dual traversal,
  * k_bp_dual.hpp: each reads two wide node records and tests up to four box pairs); 0 when the
  * per-particle walk was used. For the roofline accounting. */

@@ -187,6 +187,6 @@ def test_host_hash_sees_structured_edits():
             seen.add(he)
         assert len(seen) == len(edits) + 1
     # chunks combine by addition: the transfer paths hash piecewise
-    assert h(np.zeros(3)) != h(np.zeros(4)) and h(np.zeros(0)) == (0, 0)
+    assert h(np.zeros(0)) == (0, 0) and h(np.ones(3)) != h(np.ones(4))
     b = np.frombuffer(bytes(range(20)), dtype=np.uint8)  # a tail that is not a multiple of 8
     assert h(b) != h(b[:16]) and h(b) != h(np.concatenate([b[:19], [0]]).astype(np.uint8))
