@@ -29,6 +29,7 @@
 #include "k_propagate.hpp"
 #include "k_scan_sort.hpp"
 #include "order_api.hpp"
+#include "wave_api.hpp"
 
 // Scratch of csc_global_aabb_noalloc (the one entry point that allocates nothing): partial
 // (min, max) boxes of the block reduction. A file-scope device array: every GPU the library runs
@@ -131,6 +132,12 @@ struct csc_ctx {
     bool profiling = false;
     std::string profile_only; // when not empty: only this kernel is timed
     std::vector<csc_tape_op> tape_host; // the tape currently in the "tape_ops" buffer
+    // k_propagate_wave: the schedule of the tape it was built from (wave_tape), on the device in
+    // "wave_ops" / "wave_ops0". wave_mode: -1 read CASCADE_WAVE once; 0 off; 1 on.
+    std::vector<csc_tape_op> wave_tape;
+    csc::wave_plan wave_plan;
+    int wave_mode = -1;
+    bool pass1_wave = false; // the last pass 1 ran k_propagate_wave: the store pass then does too (same substeps)
     float4 *na_scratch = nullptr;       // device address of `scratch` on this context's device
     // csc_upload / csc_download: pinned staging mirror (grow-only), copy stream, one event per chunk
     void *stage = nullptr;
@@ -680,6 +687,7 @@ csc::prop_params make_prop_params(const csc_prop_cfg *cfg, uint32_t n, const dou
     p.pars = cfg->d_pars;
     p.npars = cfg->npars;
     p.row_cap = 0;
+    p.row_first = 0;
     p.tape = nullptr;
     p.tape_nops = p.tape_nslots = 0;
     p.tape_ws = nullptr;
@@ -767,10 +775,11 @@ int check_cfg(csc_ctx *ctx, const csc_prop_cfg *cfg)
         ctx->err = "unknown dynamics kind (built: Kepler, Kepler + J2, Kepler + J2 + drag, tape)";
         return CSC_ERR_UNSUPPORTED;
     }
-    if (cfg->dyn_kind == CSC_DYN_TAPE) {
+    if (cfg->dyn_kind == CSC_DYN_TAPE || cfg->tape != nullptr) {
+        // (a tape may come with the built-in dynamics too: the several-lanes-per-object kernel runs from it)
         // Every operation defines a new slot from earlier ones; anything else would read
         // coefficients that do not exist yet (or memory outside the workspace).
-        if (cfg->tape == nullptr || cfg->tape_nops == 0u || cfg->tape_nslots < 8u || cfg->tape_nslots > (1u << 16)) {
+        if (cfg->tape == nullptr || cfg->tape_nops == 0u || cfg->tape_nslots < 8u || cfg->tape_nslots >= 0xffffu) {
             return ctx->invalid("tape dynamics without a tape");
         }
         for (uint32_t k = 0; k < cfg->tape_nops; ++k) {
@@ -1301,6 +1310,62 @@ int csc_check_flags(csc_ctx *ctx)
 
 // ---- K1 / K2 ---------------------------------------------------------------------------
 
+// One object over several lanes, series in LDS (k_propagate_wave.hpp): every right-hand side that
+// comes with its tape, except plain Kepler (order 20). Schedules the tape when it is new, launches
+// the kernel and sets `launched`; leaves it false when the kernel does not apply.
+static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::prop_params &p, bool events, bool &launched)
+{
+    launched = false;
+    if (ctx->wave_mode < 0) {
+        const char *e = std::getenv("CASCADE_WAVE");
+        ctx->wave_mode = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    if (ctx->wave_mode != 1 || cfg->order != 20u || cfg->tape == nullptr || cfg->dyn_kind == CSC_DYN_KEPLER) {
+        return CSC_OK;
+    }
+    const int wave_ng = csc::wave_pick_ng(cfg->tape_nslots, cfg->tape_nops, cfg->order);
+    if (wave_ng == 0) {
+        return CSC_OK;
+    }
+    static_assert(sizeof(csc_tape_op) == sizeof(csc::tape_op), "tape layout");
+    const size_t bytes = static_cast<size_t>(cfg->tape_nops) * sizeof(csc_tape_op);
+    const bool fresh = ctx->wave_tape.size() != cfg->tape_nops || std::memcmp(ctx->wave_tape.data(), cfg->tape, bytes) != 0
+                       || ctx->wave_plan.ng != static_cast<uint32_t>(wave_ng) || ctx->wave_plan.nslots != cfg->tape_nslots
+                       || std::memcmp(ctx->wave_plan.rhs, cfg->tape_rhs, sizeof(cfg->tape_rhs)) != 0;
+    if (fresh) {
+        ctx->wave_tape.assign(cfg->tape, cfg->tape + cfg->tape_nops);
+        csc::wave_build_plan(reinterpret_cast<const csc::tape_op *>(cfg->tape), cfg->tape_nops, cfg->tape_nslots, cfg->tape_rhs, wave_ng,
+                             cfg->order, ctx->wave_plan);
+    }
+    const csc::wave_plan &wp = ctx->wave_plan;
+    if (wp.lds_bytes() > csc::WAVE_LDS_MAX) {
+        return CSC_OK; // (does not fit after all: the one-lane-per-object interpreter)
+    }
+    CSC_BUF(d_wops, csc::wave_op, "wave_ops", wp.ops.size());
+    CSC_BUF(d_wops0, csc::wave_op0, "wave_ops0", wp.ops0.size());
+    if (fresh) {
+        CSC_HIP(hipMemcpyAsync(d_wops, wp.ops.data(), wp.ops.size() * sizeof(csc::wave_op), hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(d_wops0, wp.ops0.data(), wp.ops0.size() * sizeof(csc::wave_op0), hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    csc::wave_sched ws{};
+    ws.ops = d_wops;
+    ws.ops0 = d_wops0;
+    ws.nrows = wp.nrows;
+    ws.nslots = wp.nslots;
+    ws.obj_doubles = wp.obj_doubles;
+    for (int c = 0; c < 7; ++c) {
+        ws.rhs[c] = wp.rhs[c];
+    }
+    hipError_t lrc = hipSuccess;
+    KT(p.nsub_in ? "k_propagate_wave_store" : "k_propagate_wave", lrc = csc::wave_launch(wave_ng, events, p, ws, wp.lds_bytes(), ctx->stream));
+    if (lrc != hipSuccess) {
+        return ctx->fail(lrc, "k_propagate_wave launch");
+    }
+    launched = true;
+    return CSC_OK;
+}
+
 static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                           int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
                           double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,
@@ -1336,26 +1401,38 @@ static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, con
     p.ubs = d_ubs;
     p.recs = d_recs;
     p.row_cap = row_cap;
+    p.row_first = (count != 0xffffffffu && row_cap != 0u) ? first : 0u; // (a range with rows: the rows are its own)
     p.tc_row = d_tc_row;
     p.tcs_xyz = d_tcs_xyz;
     p.tcs_vr = d_tcs_vr;
     p.tcoords = d_tcoords;
     const bool events = cfg->has_exit || cfg->has_reentry;
     dim3 grid(cdiv(n, 64)), block(64);
-    if (cfg->dyn_kind == CSC_DYN_TAPE) {
-        if (const int rc = bind_tape(ctx, cfg, n, p, grid)) {
-            return rc;
-        }
-    }
     // With rows: the boxes and samples come from the rows, in a kernel of their own (order 20,
     // built-in dynamics; CASCADE_BOX_KERNEL=0: fused into the integration as without rows).
     if (ctx->box_kernel < 0) {
         const char *e = std::getenv("CASCADE_BOX_KERNEL");
         ctx->box_kernel = (e && std::atoi(e) == 0) ? 0 : 1;
     }
-    const bool nobox = row_cap != 0u && ctx->box_kernel == 1 && cfg->order == 20u && cfg->dyn_kind != CSC_DYN_TAPE;
-    KT(row_cap ? "k_propagate_rows" : "k_propagate",
-       launch_propagate<false>(cfg->order, cfg->dyn_kind, events, grid, block, ctx->stream, p, nobox));
+    // (k_propagate_wave whenever the pass writes rows and the dynamics come with their tape)
+    bool waved = false;
+    if (row_cap != 0u) {
+        if (const int rc = wave_try_launch(ctx, cfg, p, events, waved)) {
+            return rc;
+        }
+    }
+    ctx->pass1_wave = waved;
+    const int wave_ng = waved ? 1 : 0;
+    const bool nobox = wave_ng != 0 || (row_cap != 0u && ctx->box_kernel == 1 && cfg->order == 20u && cfg->dyn_kind != CSC_DYN_TAPE);
+    if (wave_ng == 0) {
+        if (cfg->dyn_kind == CSC_DYN_TAPE) {
+            if (const int rc = bind_tape(ctx, cfg, n, p, grid)) {
+                return rc;
+            }
+        }
+        KT(row_cap ? "k_propagate_rows" : "k_propagate",
+           launch_propagate<false>(cfg->order, cfg->dyn_kind, events, grid, block, ctx->stream, p, nobox));
+    }
     CSC_LAUNCH_CHECK();
     if (nobox) {
         const uint64_t lanes = static_cast<uint64_t>(n) * p.nchunks;
@@ -1517,6 +1594,29 @@ int csc_propagate_range(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint3
                           d_ubs, d_recs, 0, nullptr, nullptr, nullptr, nullptr, first, count);
 }
 
+int csc_propagate_range_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
+                             const double *d_state, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
+                             double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap)
+{
+    if (row_cap == 0u) {
+        return ctx->invalid("csc_propagate_range_rows needs row_cap > 0");
+    }
+    if (first > n || count > n - first) {
+        return ctx->invalid("csc_propagate_range: the range does not lie within the particles");
+    }
+    // The rows of the range live in the context: they feed k_chunk_boxes and are not handed out
+    // (the narrow phase of a sharded superstep gets its rows from csc_propagate_store).
+    uint32_t xs = 0, vs = 0;
+    csc_tc_strides(cfg ? cfg->order : 20u, &xs, &vs);
+    const size_t rows = std::max<size_t>(static_cast<size_t>(count) * row_cap, 1);
+    CSC_BUF(d_row, uint64_t, "range_tc_row", n);
+    CSC_BUF(d_xyz, double, "range_tcs_xyz", rows * xs);
+    CSC_BUF(d_vr, double, "range_tcs_vr", rows * vs);
+    CSC_BUF(d_tco, double, "range_tcoords", rows * 2u);
+    return propagate_impl(ctx, cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, d_lbs,
+                          d_ubs, d_recs, row_cap, d_row, d_xyz, d_vr, d_tco, first, count);
+}
+
 int csc_propagate_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,
                        int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time, double *d_nf_last_t,
                        double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap,
@@ -1562,6 +1662,16 @@ int csc_propagate_store(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const
     p.tcoords = d_tcoords;
     const bool events = cfg->has_exit || cfg->has_reentry;
     dim3 grid(cdiv(n, 64)), block(64);
+    if (ctx->pass1_wave) {
+        // (the integration that counted the substeps: the same arithmetic repeats them)
+        bool waved = false;
+        if (const int rc = wave_try_launch(ctx, cfg, p, events, waved)) {
+            return rc;
+        }
+        if (waved) {
+            return CSC_OK;
+        }
+    }
     if (cfg->dyn_kind == CSC_DYN_TAPE) {
         if (const int rc = bind_tape(ctx, cfg, n, p, grid)) {
             return rc;

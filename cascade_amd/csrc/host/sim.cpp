@@ -446,6 +446,7 @@ struct sim::sim_data {
     // arrays and the device copies are current.
     std::uint64_t state_hash[2] = {0, 0}, pars_hash[2] = {0, 0};
     bool hash_valid = false;
+    bool wave_env = true, fuse_env = true; // CASCADE_WAVE / CASCADE_BP_FUSE != 0
     std::uint64_t step_counter = 0; // step() calls so far (identical on the processes of a sharded simulation)
     std::vector<std::pair<std::uint64_t, std::uint64_t>> conj_segments;
     step_stats stats;
@@ -467,7 +468,8 @@ struct sim::sim_data {
         : dyn(o.dyn), tape(o.tape), tol(o.tol), high_accuracy(o.high_accuracy), compact_mode(o.compact_mode), order(o.order),
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
           single_pass_mode(o.single_pass_mode),
-          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather), shard_chunks(o.shard_chunks), alltoall(o.alltoall)
+          shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather), shard_chunks(o.shard_chunks), alltoall(o.alltoall),
+          wave_env(o.wave_env), fuse_env(o.fuse_env)
     {
     }
     ~sim_data()
@@ -697,7 +699,10 @@ void sim::finalise_ctor(options o)
         throw std::invalid_argument("The tolerance " + fmt_d(tol) + " needs Taylor order " + std::to_string(m_data->order)
                                     + ", and the kernels are built for orders 6 to 24");
     }
-    if (m_data->order != 20u && m_data->dyn.kind != dynamics::dyn_t::tape) {
+    // The built-in perturbed dynamics (J2, J2 + drag) come with their tape as well: at order 20
+    // the several-lanes-per-object kernel (k_propagate_wave) integrates from it, the hand-unrolled
+    // kernels keep the passes without rows.
+    if (m_data->dyn.kind != dynamics::dyn_t::tape && (m_data->order != 20u || m_data->dyn.kind != dynamics::dyn_t::kepler)) {
         m_data->tape = lower_dynamics(m_data->dyn.eqs);
     }
     m_data->high_accuracy = o.high_accuracy;
@@ -706,6 +711,9 @@ void sim::finalise_ctor(options o)
     if (const char *e = std::getenv("CASCADE_SINGLE_PASS")) {
         m_data->single_pass_mode = std::atoi(e);
     }
+    // (measurement / test switches, read when the simulation is constructed)
+    m_data->wave_env = !(std::getenv("CASCADE_WAVE") && std::atoi(std::getenv("CASCADE_WAVE")) == 0);
+    m_data->fuse_env = !(std::getenv("CASCADE_BP_FUSE") && std::atoi(std::getenv("CASCADE_BP_FUSE")) == 0);
 
     verify_state_vector(*m_state);
 }
@@ -1270,7 +1278,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     cfg.d_pars = d_pars;
     cfg.npars = m_npars;
-    if (from_tape) {
+    if (from_tape || !d.tape.ops.empty()) {
         static_assert(sizeof(tape_op) == sizeof(csc_tape_op), "tape layout");
         cfg.tape = reinterpret_cast<const csc_tape_op *>(d.tape.ops.data());
         cfg.tape_nops = static_cast<std::uint32_t>(d.tape.ops.size());
@@ -1321,29 +1329,38 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
                         || (d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && !from_tape && d.sparse_likely
                             && !d.want_full_rows);
     std::uint32_t row_cap = 0;
-    if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler || from_tape)
+    // The several-lanes-per-object kernel (k_propagate_wave; every tape except plain Kepler's, order
+    // 20) always writes rows: in the first superstep of a configuration the slots are a guess, and a
+    // particle that needs more has the pass repeated with what it asked for.
+    const bool wave_ok = d.wave_env && d.order == 20u && !d.tape.ops.empty() && d.dyn.kind != dynamics::dyn_t::kepler;
+    const auto rows_fit = [&](std::uint32_t cap) { return static_cast<double>(n) * cap * (xs + vs + 2u) * 8. <= 96e9; };
+    if (!sparse && d.single_pass_mode != 0 && wave_ok && d.row_hint == 0u) {
+        row_cap = std::max(4u, nchunks0 / 2u + 3u);
+        if (!rows_fit(row_cap)) {
+            row_cap = 0;
+        }
+    } else if (!sparse && d.single_pass_mode != 0 && (d.single_pass_mode == 2 || d.dyn.kind != dynamics::dyn_t::kepler || from_tape)
         && d.row_hint != 0u) {
         row_cap = d.row_hint + std::max(2u, d.row_hint / 4u);
         if (const char *e = std::getenv("CASCADE_ROW_CAP")) {
             row_cap = std::max(1, std::atoi(e)); // (tests: slots that overflow)
         }
-        if (static_cast<double>(n) * row_cap * (xs + vs + 2u) * 8. > 96e9) {
+        if (!rows_fit(row_cap)) {
             row_cap = 0; // would not fit comfortably: two passes
         }
     }
-    double *d_txyz = nullptr, *d_tvr = nullptr, *d_tco = nullptr;
-    if (row_cap != 0u) {
-        const std::uint64_t rows = static_cast<std::uint64_t>(n) * row_cap;
-        d_txyz = d.buf<double>("tcs_xyz", rows * xs);
-        d_tvr = d.buf<double>("tcs_vr", rows * vs);
-        d_tco = d.buf<double>("tcoords", rows * 2u);
-        d.chk(csc_propagate_rows(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
-                                 d_recs, row_cap, d_tc_row, d_txyz, d_tvr, d_tco));
-    } else if (shard_prop) {
+    // Propagation of this process's range and the exchange of the per-particle records; rcap != 0:
+    // through the several-lanes-per-object kernel, with rows of the range kept inside the context.
+    const auto run_sharded = [&](std::uint32_t rcap) {
         const std::uint32_t per = (n + d.shard_n - 1u) / d.shard_n;
         const std::uint32_t first = std::min(n, d.shard_rank * per), count = std::min(per, n - first);
-        d.chk(csc_propagate_range(ctx, &cfg, n, first, count, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final,
-                                  d_lbs, d_ubs, d_recs));
+        if (rcap != 0u) {
+            d.chk(csc_propagate_range_rows(ctx, &cfg, n, first, count, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t,
+                                           d_final, d_lbs, d_ubs, d_recs, rcap));
+        } else {
+            d.chk(csc_propagate_range(ctx, &cfg, n, first, count, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final,
+                                      d_lbs, d_ubs, d_recs));
+        }
         if (chunk_mode && d.alltoall) {
             // Every process needs the per-chunk records of its own block of chunks only.
             std::vector<std::size_t> seg(d.shard_n);
@@ -1383,6 +1400,21 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
             d.stats.exchanged_bytes = static_cast<std::size_t>(per) * d.shard_n * rec;
         }
         d.stats.propagated = count;
+    };
+    std::uint32_t shard_rcap = 0;
+    if (shard_prop && wave_ok) {
+        shard_rcap = d.row_hint != 0u ? d.row_hint + std::max(2u, d.row_hint / 4u) : std::max(4u, nchunks0 / 2u + 3u);
+    }
+    double *d_txyz = nullptr, *d_tvr = nullptr, *d_tco = nullptr;
+    if (row_cap != 0u) {
+        const std::uint64_t rows = static_cast<std::uint64_t>(n) * row_cap;
+        d_txyz = d.buf<double>("tcs_xyz", rows * xs);
+        d_tvr = d.buf<double>("tcs_vr", rows * vs);
+        d_tco = d.buf<double>("tcoords", rows * 2u);
+        d.chk(csc_propagate_rows(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
+                                 d_recs, row_cap, d_tc_row, d_txyz, d_tvr, d_tco));
+    } else if (shard_prop) {
+        run_sharded(shard_rcap);
     } else {
         d.chk(csc_propagate(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs, d_recs));
     }
@@ -1392,6 +1424,22 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     csc_prop_summary summ{};
     d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+    if (shard_prop && shard_rcap != 0u && (summ.flags & CSC_ST_FLAG_ROW_OVERFLOW)) {
+        // (the same decision on every process: the summary covers all particles)
+        run_sharded(summ.max_substeps + 1u);
+        d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+    }
+    if (row_cap != 0u && (summ.flags & CSC_ST_FLAG_ROW_OVERFLOW) && wave_ok && rows_fit(summ.max_substeps + 1u)) {
+        // (the substeps were counted in full: exactly enough slots this time)
+        row_cap = summ.max_substeps + 1u;
+        const std::uint64_t rows = static_cast<std::uint64_t>(n) * row_cap;
+        d_txyz = d.buf<double>("tcs_xyz", rows * xs);
+        d_tvr = d.buf<double>("tcs_vr", rows * vs);
+        d_tco = d.buf<double>("tcoords", rows * 2u);
+        d.chk(csc_propagate_rows(ctx, &cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, d_final, d_lbs, d_ubs,
+                                 d_recs, row_cap, d_tc_row, d_txyz, d_tvr, d_tco));
+        d.chk(csc_propagate_summary(ctx, n, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_t, &summ));
+    }
     if (row_cap != 0u && (summ.flags & CSC_ST_FLAG_ROW_OVERFLOW)) {
         // A particle took more substeps than its row slots hold. The boxes of a pass with rows may
         // come from the rows (k_chunk_boxes) and are then incomplete for it: integrate again
@@ -1517,8 +1565,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     // With the pre-filter on, the box-overlap pairs are counted and filtered inside the tile kernel
     // of the traversal and only the candidates of the polynomial test are stored (csc_broad_phase_filtered).
-    static const bool fuse_env = !(std::getenv("CASCADE_BP_FUSE") && std::atoi(std::getenv("CASCADE_BP_FUSE")) == 0);
-    const bool fused = have_chunks && d.np_prefilter && d_srecs != nullptr && fuse_env;
+    const bool fused = have_chunks && d.np_prefilter && d_srecs != nullptr && d.fuse_env;
     if (fused) {
         std::uint64_t ncand = 0;
         d.chk(csc_broad_phase_filtered(ctx, n, cl, d_slbs, d_subs, d_vidx, d_active, m_conj_thresh, d_srecs, &npairs, &ncand));

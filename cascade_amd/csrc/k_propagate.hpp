@@ -109,6 +109,8 @@ struct prop_params {
     // integration into the fixed slots [i * row_cap, (i + 1) * row_cap) of particle i
     // (tcs_xyz / tcs_vr / tcoords / tc_row below), and there is no second pass.
     std::uint32_t row_cap;
+    // ... of particle i - row_first (a pass over a range of particles with rows of its own).
+    std::uint32_t row_first;
     // Pass 1 over a range of particles (propagation sharded over GPUs): lane k handles particle
     // first + k, k < n, and the per-chunk arrays hold n_total particles per chunk.
     std::uint32_t first, n_total;
@@ -766,7 +768,7 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
         ns_owned = prm.nsub_in[i];
     } else {
         if (prm.row_cap != 0u) {
-            row = static_cast<std::size_t>(i) * prm.row_cap;
+            row = static_cast<std::size_t>(i - prm.row_first) * prm.row_cap;
             prm.tc_row[i] = row;
         }
     }
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(256, 2) void k_chunk_boxes(const prop_params prm)
     double sbound = 0., sabs = 0.;
     bool visited = false, bad = false;
     dfl tc_prev = df(0.);
-    const std::size_t row0 = static_cast<std::size_t>(i) * prm.row_cap;
+    const std::size_t row0 = static_cast<std::size_t>(i - prm.row_first) * prm.row_cap;
     // The fused loop visits chunk k in the substeps with ce > tc_prev and cb < tc: the substeps from
     // the first one that ends after cb, for as long as they begin before ce. Finding the first one
     // takes the end times only; the loop below then runs once or twice per lane with (nearly) all

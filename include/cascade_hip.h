@@ -416,6 +416,15 @@ int csc_narrow_phase_view(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_
 int csc_propagate_range(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
                         const double *d_state, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
                         double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs);
+/* The same with dense-output rows written on the way into row_cap fixed slots per particle of the
+ * range, kept inside the context: the pass then runs the several-lanes-per-object kernel where
+ * the dynamics come with their tape (every right-hand side except plain Kepler) and takes the
+ * boxes and trajectory records from the rows. A particle with more substeps than row_cap raises
+ * CSC_ST_FLAG_ROW_OVERFLOW in its status (the caller repeats the pass with the substep count the
+ * summary reports). */
+int csc_propagate_range_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
+                             const double *d_state, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
+                             double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap);
 size_t csc_shard_record_bytes(uint32_t nchunks);
 int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t nchunks, const uint32_t *d_nsub,
                    const int32_t *d_status, const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,

@@ -5,6 +5,8 @@ broad-phase pair counts, same conjunction sets, states and times within 1e-9 rel
 import numpy as np
 import pytest
 
+from _tol import states_close
+
 pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
@@ -35,7 +37,7 @@ def _same_step(g, o, og, oo):
     else:
         assert gi == oi
     assert abs(g.time - o.time) <= RTOL * max(1.0, abs(o.time))
-    assert np.all(np.abs(g.state - o.state) <= RTOL * np.maximum(1.0, np.abs(o.state)))
+    assert states_close(g.state, o.state, RTOL)
     assert g.last_bp_pairs == int(o.stage_times()["n_bp_pairs"])
 
 
