@@ -1320,7 +1320,9 @@ static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::pro
         const char *e = std::getenv("CASCADE_WAVE");
         ctx->wave_mode = (e && std::atoi(e) == 0) ? 0 : 1;
     }
-    if (ctx->wave_mode != 1 || cfg->order != 20u || cfg->tape == nullptr || cfg->dyn_kind == CSC_DYN_KEPLER) {
+    // (the hand-unrolled kernels of the built-in dynamics are faster than this one: 16 against
+    // ~170 ns per object-substep for J2 + drag, whose generic tape has 83 operations for 17 hand-picked series)
+    if (ctx->wave_mode != 1 || cfg->order != 20u || cfg->tape == nullptr || cfg->dyn_kind != CSC_DYN_TAPE) {
         return CSC_OK;
     }
     const int wave_ng = csc::wave_pick_ng(cfg->tape_nslots, cfg->tape_nops, cfg->order);
@@ -1338,8 +1340,17 @@ static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::pro
                              cfg->order, ctx->wave_plan);
     }
     const csc::wave_plan &wp = ctx->wave_plan;
+    if (fresh && std::getenv("CASCADE_WAVE_DEBUG")) {
+        std::fprintf(stderr, "[wave] tape: %u operations, %u slots -> %u groups per object, %u rows, %zu bytes of LDS per wave\n", cfg->tape_nops,
+                     cfg->tape_nslots, wp.ng, wp.nrows, wp.lds_bytes());
+    }
+    // Two waves per compute unit at least: beyond that (simple_earth with every term: 451 operations,
+    // 110 KB per object) the one-lane-per-object interpreter with its global workspace is faster.
+    if (wp.lds_bytes() > csc::WAVE_LDS_MAX / 2u && !std::getenv("CASCADE_WAVE_NG")) {
+        return CSC_OK;
+    }
     if (wp.lds_bytes() > csc::WAVE_LDS_MAX) {
-        return CSC_OK; // (does not fit after all: the one-lane-per-object interpreter)
+        return CSC_OK;
     }
     CSC_BUF(d_wops, csc::wave_op, "wave_ops", wp.ops.size());
     CSC_BUF(d_wops0, csc::wave_op0, "wave_ops0", wp.ops0.size());

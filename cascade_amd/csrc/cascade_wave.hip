@@ -42,7 +42,7 @@ void lower_op(const tape_op &o, std::vector<sched_item> &out)
     it.z.c = o.c;
     it.z.pm_kind = PM_ONE;
     it.z.pm_slot = 0;
-    std::uint32_t sa = 0, sb = 0, l1 = NOSLOT, l2 = NOSLOT, jlo = 0, jhi_off = 0, fl = WF_VALID;
+    std::uint32_t sa = 0, sb = 0, l1 = 0, l2 = 0, jlo = 0, jhi_off = 0, fl = WF_VALID; // (no linear term: slot 0 x 0)
     int a1 = 0, a2 = 0, sg = 0;
     double wa = 0., wb = 0.;
     auto sum = [&](std::int32_t A, std::int32_t B, std::uint32_t lo, std::uint32_t hoff, int sign, bool wc) {
@@ -176,7 +176,7 @@ int wave_pick_ng(std::uint32_t nslots, std::uint32_t nops, std::uint32_t order)
     const std::size_t L = order + 1u;
     int best = 0;
     for (const int ng : {1, 2, 4, 8}) {
-        const std::size_t obj = (static_cast<std::size_t>(nslots) * L + 2u * nops + 8u + L + 1u) * sizeof(double);
+        const std::size_t obj = (static_cast<std::size_t>(nslots + 1u) * L + 2u * nops + 8u + L + 1u) * sizeof(double) + (2u * nops + 8u) * 32u / (64u / (8u * static_cast<unsigned>(ng)));
         const std::size_t per_wave = obj * (64u / (8u * static_cast<unsigned>(ng)));
         if (per_wave > WAVE_LDS_MAX) {
             continue;
@@ -231,7 +231,7 @@ void wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
                 out.ops0.resize(static_cast<std::size_t>(rows + 1u) * ng);
                 for (int g = 0; g < ng; ++g) {
                     wave_op e{};
-                    e.l = NOSLOT | (NOSLOT << 16);
+                    e.d = nslots; // (an empty place: the spare slot behind the series takes what it computes)
                     out.ops[static_cast<std::size_t>(rows) * ng + g] = e;
                     out.ops0[static_cast<std::size_t>(rows) * ng + g] = wave_op0{};
                 }
@@ -249,7 +249,7 @@ void wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
     }
     out.nrows = rows;
     const std::uint32_t L = order + 1u;
-    out.obj_doubles = (nslots * L + rows * static_cast<std::uint32_t>(ng) + L + 1u) & ~1u;
+    out.obj_doubles = ((nslots + 1u) * L + rows * static_cast<std::uint32_t>(ng) + L + 1u) & ~1u;
     for (int c = 0; c < 7; ++c) {
         out.rhs[c] = rhs[c];
     }

@@ -699,10 +699,7 @@ void sim::finalise_ctor(options o)
         throw std::invalid_argument("The tolerance " + fmt_d(tol) + " needs Taylor order " + std::to_string(m_data->order)
                                     + ", and the kernels are built for orders 6 to 24");
     }
-    // The built-in perturbed dynamics (J2, J2 + drag) come with their tape as well: at order 20
-    // the several-lanes-per-object kernel (k_propagate_wave) integrates from it, the hand-unrolled
-    // kernels keep the passes without rows.
-    if (m_data->dyn.kind != dynamics::dyn_t::tape && (m_data->order != 20u || m_data->dyn.kind != dynamics::dyn_t::kepler)) {
+    if (m_data->order != 20u && m_data->dyn.kind != dynamics::dyn_t::tape) {
         m_data->tape = lower_dynamics(m_data->dyn.eqs);
     }
     m_data->high_accuracy = o.high_accuracy;
@@ -1278,7 +1275,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     cfg.d_pars = d_pars;
     cfg.npars = m_npars;
-    if (from_tape || !d.tape.ops.empty()) {
+    if (from_tape) {
         static_assert(sizeof(tape_op) == sizeof(csc_tape_op), "tape layout");
         cfg.tape = reinterpret_cast<const csc_tape_op *>(d.tape.ops.data());
         cfg.tape_nops = static_cast<std::uint32_t>(d.tape.ops.size());
@@ -1329,10 +1326,10 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
                         || (d.rows_on_demand && d.np_prefilter && d.dyn.kind == dynamics::dyn_t::kepler && !from_tape && d.sparse_likely
                             && !d.want_full_rows);
     std::uint32_t row_cap = 0;
-    // The several-lanes-per-object kernel (k_propagate_wave; every tape except plain Kepler's, order
-    // 20) always writes rows: in the first superstep of a configuration the slots are a guess, and a
+    // The several-lanes-per-object kernel (k_propagate_wave: tape dynamics at order 20; the
+    // hand-unrolled Kepler / J2 / J2 + drag kernels are faster than it) always writes rows: in the first superstep of a configuration the slots are a guess, and a
     // particle that needs more has the pass repeated with what it asked for.
-    const bool wave_ok = d.wave_env && d.order == 20u && !d.tape.ops.empty() && d.dyn.kind != dynamics::dyn_t::kepler;
+    const bool wave_ok = d.wave_env && d.order == 20u && !d.tape.ops.empty() && d.dyn.kind == dynamics::dyn_t::tape;
     const auto rows_fit = [&](std::uint32_t cap) { return static_cast<double>(n) * cap * (xs + vs + 2u) * 8. <= 96e9; };
     if (!sparse && d.single_pass_mode != 0 && wave_ok && d.row_hint == 0u) {
         row_cap = std::max(4u, nchunks0 / 2u + 3u);

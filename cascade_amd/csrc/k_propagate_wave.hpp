@@ -40,7 +40,7 @@ namespace csc
 // Orders >= 1 of one scheduled operation, 32 bytes.
 struct wave_op {
     std::uint32_t s;   // sa | sb << 16: operands of the sum, A indexed by j, B by n - j
-    std::uint32_t l;   // l1 | l2 << 16: linear terms (0xffff: none)
+    std::uint32_t l;   // l1 | l2 << 16: linear terms (none: slot 0 with coefficient 0)
     std::uint32_t d;   // dst | jlo << 16 | jhi_off << 20 (sum over j = jlo .. n - jhi_off)
     std::uint32_t f;   // int8 a1 | int8 a2 << 8 | int8 sg << 16 | flags << 24
     double wa, wb;     // weight of term j: n wa + j wb + wc (wc = flag)
@@ -98,6 +98,24 @@ CSC_DEV void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Terminal event on [0, h): the polynomial g (in LDS) through the interval test, the first node of
+// the Descartes search and, when neither dismisses it, the full root isolation. (Inlined: out of
+// line the kernel is charged the callee's registers all the same, and a call under a partial
+// EXEC mask is what k_propagate.hpp avoids on purpose.)
+template <int P>
+CSC_DEV double wave_event_root(const double *gs, double h, int direction, int *flags)
+{
+    double g[P + 1];
+#pragma unroll
+    for (int n = 0; n <= P; ++n) {
+        g[n] = gs[n];
+    }
+    if (fex_excluded<P>(g, h) || descartes_no_root<P>(g, h)) {
+        return -1.;
+    }
+    return event_first_root<P>(g, h, direction, flags);
+}
+
 template <int P, int NG, bool EVENTS>
 __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, const wave_sched sc)
 {
@@ -109,9 +127,16 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
     const int sub = lane & 7, grp = (lane >> 3) % NG, ow = lane / LPO, lo = lane % LPO;
     const unsigned long long omask = (LPO == 64 ? ~0ull : ((1ull << LPO) - 1ull)) << (ow * LPO);
     double *W = lds + static_cast<std::size_t>(ow) * sc.obj_doubles;
-    double *pm = W + static_cast<std::size_t>(sc.nslots) * L; // [nrows][NG]
+    double *pm = W + static_cast<std::size_t>(sc.nslots + 1u) * L; // [nrows][NG] (behind the series and one spare slot)
     double *gs = pm + static_cast<std::size_t>(sc.nrows) * NG; // [L] event polynomial / broadcast scratch
-    const wave_op *ops = sc.ops + grp;
+    // The schedule of the orders >= 1 is read nrows x (P - 1) times per substep: a copy in LDS,
+    // behind the objects' series (2 x 16 bytes per row and group, the same address for 8 lanes).
+    uint4 *lops = reinterpret_cast<uint4 *>(lds + static_cast<std::size_t>(OPW) * sc.obj_doubles);
+    for (std::uint32_t k = lane; k < sc.nrows * NG * 2u; k += 64u) {
+        lops[k] = reinterpret_cast<const uint4 *>(sc.ops)[k];
+    }
+    wave_lds_sync();
+    const uint4 *ops = lops + 2 * grp;
     const wave_op0 *ops0 = sc.ops0 + grp;
     const dfl init_time{prm.init_hi, prm.init_lo};
     const dfl t_end = df_add(init_time, df(prm.delta_t));
@@ -237,46 +262,44 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
             for (int n = 1; n < P; ++n) {
                 const double dn = static_cast<double>(n), rn = 1. / dn;
                 const int trips = (n + 8) >> 3;
+                uint4 nx0 = ops[0], nx1 = ops[1];
                 for (std::uint32_t r = 0; r < sc.nrows; ++r) {
-                    const wave_op o = ops[static_cast<std::size_t>(r) * NG];
-                    const std::uint32_t fl = o.f >> 24;
-                    const int sa = o.s & 0xffffu, sb = o.s >> 16;
-                    const int l1 = o.l & 0xffffu, l2 = o.l >> 16;
-                    const int dst = o.d & 0xffffu, jlo = (o.d >> 16) & 0xf, jhi = n - static_cast<int>((o.d >> 20) & 0xf);
-                    const double a1 = static_cast<double>(static_cast<std::int8_t>(o.f & 0xffu));
-                    const double a2 = static_cast<double>(static_cast<std::int8_t>((o.f >> 8) & 0xffu));
-                    const double sg = static_cast<double>(static_cast<std::int8_t>((o.f >> 16) & 0xffu));
+                    // (the next row's descriptor is requested before this row's work starts)
+                    const uint4 o0 = nx0, o1 = nx1;
+                    const std::uint32_t rn1 = r + 1u < sc.nrows ? r + 1u : 0u;
+                    nx0 = ops[rn1 * (2 * NG)];
+                    nx1 = ops[rn1 * (2 * NG) + 1];
+                    const std::uint32_t of = o0.w, fl = of >> 24;
+                    const int sa = o0.x & 0xffffu, sb = o0.x >> 16;
+                    const int l1 = o0.y & 0xffffu, l2 = o0.y >> 16;
+                    const int dst = o0.z & 0xffffu, jlo = (o0.z >> 16) & 0xf, jhi = n - static_cast<int>((o0.z >> 20) & 0xf);
+                    const double a1 = static_cast<double>(static_cast<std::int8_t>(of & 0xffu));
+                    const double a2 = static_cast<double>(static_cast<std::int8_t>((of >> 8) & 0xffu));
+                    const double sg = static_cast<double>(static_cast<std::int8_t>((of >> 16) & 0xffu));
+                    const double owa = __hiloint2double(static_cast<int>(o1.y), static_cast<int>(o1.x));
+                    const double owb = __hiloint2double(static_cast<int>(o1.w), static_cast<int>(o1.z));
+                    // No branches below except the wave-uniform one around the sum: a row without a
+                    // linear term reads slot 0 with coefficient 0, an empty place in a row writes
+                    // to the spare slot behind the series, all 8 lanes store the (same) result.
+                    const double l1v = W[l1 * L + n], l2v = W[l2 * L + n], pmv = pm[r * NG + grp];
                     double acc = 0.;
                     if (__any((fl & WF_SUM) != 0u)) {
-                        const double wn = fma(dn, o.wa, (fl & WF_WC) ? 1. : 0.);
+                        const double wn = fma(dn, owa, (fl & WF_WC) ? 1. : 0.);
                         const double *pa = W + sa * L, *pb = W + sb * L + n;
                         for (int t = 0; t < trips; ++t) {
                             const int j = jlo + sub + 8 * t;
                             const bool ok = (fl & WF_SUM) != 0u && j <= jhi;
                             const int jj = ok ? j : jlo;
                             const double av = pa[jj], bv = pb[-jj];
-                            const double w = fma(static_cast<double>(jj), o.wb, wn);
+                            const double w = fma(static_cast<double>(jj), owb, wn);
                             acc = ok ? fma(w * av, bv, acc) : acc;
                         }
                         acc = group8_sum(acc);
                     }
-                    double lin = 0.;
-                    if (l1 != 0xffff) {
-                        lin = a1 * W[l1 * L + n];
-                    }
-                    if (l2 != 0xffff) {
-                        lin = fma(a2, W[l2 * L + n], lin);
-                    }
-                    double res = fma(sg, acc, lin) * pm[r * NG + grp];
-                    if (fl & WF_DIVN) {
-                        res *= rn;
-                    }
-                    if (fl & WF_TIME) {
-                        res = n == 1 ? 1. : 0.;
-                    }
-                    if ((fl & WF_VALID) && sub == 0) {
-                        W[dst * L + n] = res;
-                    }
+                    double res = fma(sg, acc, fma(a2, l2v, a1 * l1v)) * pmv;
+                    res = (fl & WF_DIVN) ? res * rn : res;
+                    res = (fl & WF_TIME) ? (n == 1 ? 1. : 0.) : res;
+                    W[dst * L + n] = res;
                     wave_lds_sync();
                 }
                 if (lo < 7) {
@@ -343,18 +366,11 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
                     }
                     wave_lds_sync();
                     if (alive && !stop_nf && h > 0.) {
-                        double g[P + 1];
-#pragma unroll
-                        for (int n = 0; n <= P; ++n) {
-                            g[n] = gs[n];
-                        }
-                        if (!fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
-                            const double rt = event_first_root<P>(g, h, e == 0 ? 1 : -1, &flags);
-                            if (rt >= 0. && (!ev_found || rt < ev_t)) {
-                                ev_found = true;
-                                ev_t = rt;
-                                ev_idx = idx;
-                            }
+                        const double rt = wave_event_root<P>(gs, h, e == 0 ? 1 : -1, &flags);
+                        if (rt >= 0. && (!ev_found || rt < ev_t)) {
+                            ev_found = true;
+                            ev_t = rt;
+                            ev_idx = idx;
                         }
                     }
                     idx = 1;

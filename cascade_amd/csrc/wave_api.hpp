@@ -22,7 +22,8 @@ struct wave_plan {
     std::int32_t rhs[7] = {};
     [[nodiscard]] std::size_t lds_bytes() const
     {
-        return static_cast<std::size_t>(64u / (8u * ng)) * obj_doubles * sizeof(double);
+        // (the objects' series, then the schedule of the orders >= 1)
+        return static_cast<std::size_t>(64u / (8u * ng)) * obj_doubles * sizeof(double) + static_cast<std::size_t>(nrows) * ng * 32u;
     }
 };
 

@@ -27,7 +27,7 @@ if which.startswith("leo_"):
     npars = dyn.tape["npars"]
     pars = np.concatenate([bstar, np.full((n, 1), 0.02)], axis=1)[:, :npars].copy()
     # benchmark/2022_leo_pop.cpp:126,165,223,297: ct = 185.5663 s, reentry at Re + 150 km
-    s = sim(st, 185.5663, dyn=dyn, pars=pars, n_par_ct=C, reentry_radius=6378136.3 + 150e3, conj_thresh=float(os.environ.get("CONJ", "0")))
+    s = sim(st, 185.5663, dyn=dyn, pars=pars, n_par_ct=C, reentry_radius=0.0 if os.environ.get("NOEV") else 6378136.3 + 150e3, conj_thresh=float(os.environ.get("CONJ", "0")))
 elif which == "haumea":
     dyn, k = haumea_dynamics()
     s = sim(haumea_ring(n), 5000.0, dyn=dyn, n_par_ct=C, reentry_radius=[k["ra"], k["rb"], k["rc"]], exit_radius=k["a_s"] * 10)

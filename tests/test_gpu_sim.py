@@ -306,7 +306,7 @@ def test_drag_decays_and_reenters():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,wave", [("j2drag", 0), ("tape", 0), ("j2drag", 1), ("tape", 1)])
+@pytest.mark.parametrize("kind,wave", [("j2drag", 0), ("tape", 0), ("tape", 1)])
 def test_single_pass_rows_change_nothing(kind, wave, monkeypatch):
     """Dynamics other than plain Kepler write their dense-output rows during the one integration
     (csc_propagate_rows) instead of re-integrating in a second pass. With the one-lane-per-object
@@ -376,11 +376,11 @@ def test_single_pass_rows_change_nothing(kind, wave, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["kepler", "j2drag", "j2drag_wave"])
+@pytest.mark.parametrize("kind", ["kepler", "j2drag", "tape_wave"])
 def test_row_overflow_falls_back(kind, monkeypatch):
     """A particle that takes more substeps than it has row slots: its rows, and the boxes computed
     from them (k_chunk_boxes), are incomplete; the superstep is integrated again without rows and
-    gives the same events and states as a run whose slots suffice. (j2drag_wave: the several-lanes-
+    gives the same events and states as a run whose slots suffice. (tape_wave: the several-lanes-
     per-object kernel counts the substeps in full and is run again with exactly enough slots.)"""
     from cascade_amd import _capi, dynamics, sim
     from cascade_amd.workloads import leo_si_population, random_leo_pop_kep
@@ -392,9 +392,9 @@ def test_row_overflow_falls_back(kind, monkeypatch):
     else:
         st, pars = leo_si_population(5000, seed=3)
         st[:, 6] *= 200.0
-        args, kw = (st, 185.5663), dict(dyn=dynamics.simple_earth(C22S22=False), pars=pars, n_par_ct=6, conj_thresh=20e3)
+        args, kw = (st, 185.5663), dict(dyn=dynamics.simple_earth(C22S22=(kind == "tape_wave")), pars=pars, n_par_ct=6, conj_thresh=20e3)
     monkeypatch.setenv("CASCADE_ROWS_ON_DEMAND", "0")  # (Kepler: rows for every particle, written in pass 1)
-    monkeypatch.setenv("CASCADE_WAVE", "1" if kind == "j2drag_wave" else "0")
+    monkeypatch.setenv("CASCADE_WAVE", "1" if kind == "tape_wave" else "0")
     a = sim(args[0].copy(), args[1], **kw)
     monkeypatch.setenv("CASCADE_ROW_CAP", "1")
     b = sim(args[0].copy(), args[1], **kw)
@@ -413,7 +413,7 @@ def test_row_overflow_falls_back(kind, monkeypatch):
             for s in (a, b):
                 s.remove_particles([ii] if isinstance(ii, int) else list(ii))
     prof = ctx.profile_get()
-    if kind == "j2drag_wave":
+    if kind == "tape_wave":
         # supersteps 2 and 3 had one slot each, overflowed and ran again with the slots they needed
         assert prof["k_propagate_wave"][0] >= 5 and "k_propagate" not in prof, {k: v[0] for k, v in prof.items() if "propagate" in k}
         return
