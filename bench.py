@@ -45,11 +45,9 @@ TU_SECONDS = 806.81  # test/last_bit_flip.cpp:61
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VEC_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 P = 20  # Taylor order at tol = DBL_EPSILON
-# k_bp_tiles is bound by VALU issue, not by bytes: 173 VALU wave-instructions per batch of 8 tiles
-# (SQ_INSTS_VALU / batches, profiles/r02i_pmc_tiles.txt), one wave64 VALU instruction per 4 clocks
-# and SIMD, 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
-TILES_PER_BATCH = 8
-TILE_VALU_PER_BATCH = 182
+# k_bp_tiles issues far more instructions than its bytes suggest: its VALU wave-instruction count per
+# launch comes from a PMC run of THIS configuration (profiles/pmc_tiles.sh -> profiles/*_tiles_valu.json);
+# one wave64 VALU instruction per 4 clocks and SIMD, 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
 VALU_PEAK_GINST = 1024 * 2.4 / 4  # 614.4 G wave-instructions/s
 
 
@@ -93,8 +91,11 @@ BYTES = {
     # K6 = 44 B x nodes visited + 8 B x pairs; the dual traversal visits two nodes per node pair
     # and ends in tiles (8 B each) when k_bp_tiles is on, in pairs otherwise.
     "k_bp_dual": lambda u: u["bp_node_pairs"] * 2 * 44 + (u["bp_tiles"] * 8 if u["bp_tiles"] else u["pairs"] * 8),
-    # every tile record once, every particle's box + flags once (36 B; the tiles share them), every pair out
-    "k_bp_tiles": lambda u: u["bp_tiles"] * 8 + u["n"] * u["nchunks"] * 36 + u["pairs"] * 8,
+    # every tile record once, every particle's box + flags once (36 B; the tiles share them); then either
+    # every pair out (csc_broad_phase) or, filtered on chip (csc_broad_phase_filtered, what step() runs),
+    # every trajectory record once (64 B) and the surviving candidates out (16 B)
+    "k_bp_tiles": lambda u: u["bp_tiles"] * 8 + u["n"] * u["nchunks"] * 36
+    + (u["n"] * u["nchunks"] * 64 + u["np_candidates"] * 16 if u.get("bp_fused") else u["pairs"] * 8),
     # single-pass rows (every object's substep rows written while it is integrated; the boxes and
     # records are k_chunk_boxes' since round 2: state in, final state out, the rows out)
     "k_propagate_rows": lambda u: u["n"] * (56 + 48 + 28) + u["substeps"] * (1176 + 16),
@@ -125,6 +126,22 @@ def measured_traffic(kernel, workload):
     return best
 
 
+def measured_valu(kernel, workload):
+    """VALU wave-instructions per launch of `kernel` from the newest profiles/*_valu.json (a PMC
+    run, profiles/pmc_tiles.sh) whose workload string matches this run; None otherwise."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and kernel in d.get("kernels", {}):
+            best = (d["kernels"][kernel]["valu_per_launch"], os.path.basename(path))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +152,7 @@ def main():
     ap.add_argument("--n-par-ct", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-sync-leg", action="store_true")
+    ap.add_argument("--no-ct-sweep", action="store_true")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded")
     ap.add_argument("--replicate-propagation", action="store_true",
                     help="N > 1: every rank integrates all objects (no all-gather of the per-object records)")
@@ -279,6 +297,7 @@ def main():
         bp_node_pairs=s.last_bp_node_pairs,
         bp_tiles=s.last_bp_tiles,
         bp_nodes_visited=0,
+        bp_fused=int(os.environ.get("CASCADE_BP_FUSE", "1") != "0"),
     )
     if dom == "k_broad_phase":
         units["bp_nodes_visited"] = s.bp_nodes_visited()
@@ -307,13 +326,13 @@ def main():
             if t_f >= t_b:
                 r.update(bound="fp64_valu", achieved=round(tf, 3), peak=FP64_VEC_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_VEC_PEAK_TFLOPS, 5), hbm_frac=round(t_b / (avg_ms * 1e-3), 5))
         if name == "k_bp_tiles" and units["bp_tiles"]:
-            # The bytes above are what the kernel has to move; what bounds it is instruction issue.
-            ginst = units["bp_tiles"] / TILES_PER_BATCH * TILE_VALU_PER_BATCH / per_step_launches / (avg_ms * 1e-3) / 1e9
-            r["valu_issue"] = dict(valu_wave_instructions_per_launch=int(units["bp_tiles"] / TILES_PER_BATCH * TILE_VALU_PER_BATCH / per_step_launches),
-                                   achieved_Ginst=round(ginst, 1), peak_Ginst=VALU_PEAK_GINST, frac=round(ginst / VALU_PEAK_GINST, 5),
-                                   source="182 VALU instructions per batch of 8 tiles: SQ_INSTS_VALU of profiles/r02i_pmc_tiles.txt")
-            r.update(bound="valu_issue", hbm_frac=r["frac"], hbm_achieved_GBps=r["achieved"], achieved=round(ginst, 1), peak=VALU_PEAK_GINST,
-                     unit="G wave-instructions/s", frac=round(ginst / VALU_PEAK_GINST, 5))
+            # SURVEY 8(d) bounds K6 by HBM bytes: that is `frac`. What the kernel is busy with is
+            # instruction issue: reported beside it, from a PMC run of the same configuration.
+            v = measured_valu(name, workload)
+            if v is not None:
+                ginst = v[0] / (avg_ms * 1e-3) / 1e9
+                r["valu_issue"] = dict(valu_wave_instructions_per_launch=int(v[0]), achieved_Ginst=round(ginst, 1), peak_Ginst=VALU_PEAK_GINST,
+                                       frac=round(ginst / VALU_PEAK_GINST, 5), source="SQ_INSTS_VALU per launch, profiles/" + v[1])
         t = measured_traffic(name, workload)
         if t is not None:
             tb = t[0]["traffic_bytes"]
@@ -401,6 +420,34 @@ def main():
         w1 = time.perf_counter() - t1
         out["n_par_ct_1"] = {"ms_per_step": round(w1 / k1 * 1e3, 4), "value": round(N * (c1.time - ts1) * TU_SECONDS / 86400.0 / w1, 2), "unit": "object-days/s", "steps": k1}
         del c1
+
+    if world == 1 and not args.no_ct_sweep:
+        # "also report a tuned ct" (results do not depend on ct,
+        # doc/tutorials/quickstart.ipynb:191). Same superstep length (ct x n_par_ct), shorter chunks.
+        sweep = [{"ct": args.ct, "n_par_ct": args.n_par_ct, "ms_per_step": out["ms_per_step"], "value": out["value"],
+                  "aabb_pairs_per_particle_per_chunk": round(pairs_all / N / args.n_par_ct, 3)}]
+        for div in (2, 4):
+            ct_k, c_k = args.ct / div, args.n_par_ct * div
+            sk = sim(st, ct_k, n_par_ct=c_k, device=local_rank)
+            sk.host_sync = False
+            for _ in range(3):
+                sk.step()
+            skx = _capi.Context.from_handle(sk._hip_context)
+            skx.sync()
+            t1, ts1, k1, pk = time.perf_counter(), sk.time, 6, 0
+            for _ in range(k1):
+                sk.step()
+                pk += sk.last_bp_pairs
+            skx.sync()
+            w1 = time.perf_counter() - t1
+            sweep.append({"ct": ct_k, "n_par_ct": c_k, "ms_per_step": round(w1 / k1 * 1e3, 4),
+                          "value": round(N * (sk.time - ts1) * TU_SECONDS / 86400.0 / w1, 2),
+                          "aabb_pairs_per_particle_per_chunk": round(pk / k1 / N / c_k, 3)})
+            del sk
+        out["ct_sweep"] = sweep
+        best = max(sweep, key=lambda e: e["value"])
+        out["tuned_ct"] = {"ct": best["ct"], "n_par_ct": best["n_par_ct"], "value": best["value"], "unit": "object-days/s",
+                           "note": "best of ct_sweep; `value` above stays the ct = %g figure" % args.ct}
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, st_w, t_w, pairs_by_step)
