@@ -123,6 +123,12 @@ SYMBOLS = {
     "csc_bvh_build": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "csc_bvh_export": (_i32, [_vp, _u32, _vp, _u64, C.POINTER(_u64)]),
     "csc_broad_phase": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "csc_narrow_phase_lazy": (_i32, [_vp, _i32]),
+    "csc_narrow_phase_counts": (_i32, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_i32)]),
+    "csc_conj_store_append": (_i32, [_vp, _u64]),
+    "csc_conj_store_size": (_u64, [_vp]),
+    "csc_conj_store_download": (_i32, [_vp, _vp]),
+    "csc_conj_store_reset": (_i32, [_vp, _i32]),
     "csc_broad_phase_filtered": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, C.c_double, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "csc_set_shard": (_i32, [_vp, _u32, _u32]),
     "csc_set_chunk_map": (_i32, [_vp, _u32, _u32]),

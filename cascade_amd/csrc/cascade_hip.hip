@@ -111,6 +111,13 @@ struct csc_ctx {
     // of 128-byte records per superstep), grow-only.
     csc_conjunction *conj = nullptr;
     size_t conj_cap = 0, conj_count = 0;
+    // Lazy mode (csc_narrow_phase_lazy): a large, device-sorted conjunction list stays on the device
+    // (conj_dev, in "np_conj_sorted") until somebody asks for the host copy; csc_conj_store_* keep the
+    // records of successive supersteps in a device-resident store.
+    bool conj_lazy = false, conj_host_valid = true;
+    const csc_conjunction *conj_dev = nullptr;
+    csc_conjunction *cstore = nullptr;
+    size_t cstore_cap = 0, cstore_n = 0;
     uint64_t np_candidates = 0; // pairs that reached the polynomial test in the last narrow phase
     uint32_t np_attempts = 0;   // passes the last narrow-phase call needed (1 = no list overflowed)
     int dt_levels = 0;          // levels with a non-empty frontier in the last dual traversal
@@ -897,6 +904,10 @@ void csc_ctx_destroy(csc_ctx *ctx)
     }
     if (ctx->d_flags) {
         (void)hipFree(ctx->d_flags);
+    }
+    if (ctx->cstore) {
+        (void)hipFree(ctx->cstore);
+        ctx->cstore = nullptr;
     }
     if (ctx->conj) {
         (void)hipHostFree(ctx->conj);
@@ -2643,6 +2654,37 @@ struct np_source {
     uint64_t npairs = 0; // number of pairs of the source (capacity bound for the candidates)
 };
 
+// The pinned host array of the last narrow phase's conjunction records, for at least `count` of them.
+static int conj_pinned(csc_ctx *ctx, size_t count)
+{
+    if (count > ctx->conj_cap) {
+        if (ctx->conj) {
+            (void)hipHostFree(ctx->conj);
+            ctx->conj = nullptr;
+            ctx->conj_cap = 0;
+        }
+        const size_t want = count + count / 2u + 1024u;
+        CSC_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->conj), want * sizeof(csc_conjunction), hipHostMallocDefault));
+        ctx->conj_cap = want;
+    }
+    return CSC_OK;
+}
+
+// Lazy mode: the host copy of a list that was left on the device.
+static int conj_materialise(csc_ctx *ctx)
+{
+    if (ctx->conj_host_valid || ctx->conj_dev == nullptr) {
+        return CSC_OK;
+    }
+    if (const int rc = conj_pinned(ctx, ctx->conj_count)) {
+        return rc;
+    }
+    CSC_HIP(hipMemcpyAsync(ctx->conj, ctx->conj_dev, ctx->conj_count * sizeof(csc_conjunction), hipMemcpyDeviceToHost, ctx->stream));
+    CSC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->conj_host_valid = true;
+    return CSC_OK;
+}
+
 static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, double delta_t, double init_time_hi,
                        double init_time_lo, double conj_thresh, uint32_t order, const double *d_state,
                        const uint8_t *d_active, const uint64_t *d_tc_row, const uint32_t *d_nsub, const double *d_tcs_xyz,
@@ -2656,6 +2698,8 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
     }
     ctx->coll.clear();
     ctx->conj_count = 0;
+    ctx->conj_dev = nullptr;
+    ctx->conj_host_valid = true;
     ctx->np_candidates = 0;
     *n_coll = 0;
     *n_conj = 0;
@@ -2823,25 +2867,23 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
         if (h[0] <= coll_cap && h[1] <= conj_cap && h[3] <= surv_cap && h[4] <= defer_cap && h[5] <= cand_cap) {
             ctx->np_candidates = h[5];
             ctx->coll.resize(h[0]);
-            if (h[1] > ctx->conj_cap) {
-                if (ctx->conj) {
-                    (void)hipHostFree(ctx->conj);
-                    ctx->conj = nullptr;
-                    ctx->conj_cap = 0;
-                }
-                const size_t want = static_cast<size_t>(h[1]) + h[1] / 2u + 1024u;
-                CSC_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->conj), want * sizeof(csc_conjunction), hipHostMallocDefault));
-                ctx->conj_cap = want;
-            }
             ctx->conj_count = h[1];
+            // Large conjunction lists are put in time order on the device (radix sort of the time
+            // keys, gather of the 128-byte records); ties and small lists are ordered on the host.
+            const bool dev_sorted = h[1] > 32768u;
+            bool lazy = ctx->conj_lazy && dev_sorted;
+            ctx->conj_dev = nullptr;
+            ctx->conj_host_valid = true;
+            if (!lazy) {
+                if (const int rc = conj_pinned(ctx, h[1])) {
+                    return rc;
+                }
+            }
             lap("pinned alloc");
             if (h[0]) {
                 CSC_HIP(hipMemcpyAsync(ctx->coll.data(), d_coll, h[0] * sizeof(csc::coll_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
             }
-            // Large conjunction lists are put in time order on the device (radix sort of the time
-            // keys, gather of the 128-byte records); ties and small lists are ordered on the host.
-            const bool dev_sorted = h[1] > 32768u;
             uint32_t n_ties = 0;
             if (dev_sorted) {
                 const uint32_t nc = h[1];
@@ -2862,7 +2904,23 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                 KT("k_count_ties", hipLaunchKernelGGL(k_count_ties, dim3(cdiv(nc, 256)), dim3(256), 0, ctx->stream, nc, kres, d_cnt + 7));
                 CSC_LAUNCH_CHECK();
                 CSC_HIP(hipMemcpyAsync(&n_ties, d_cnt + 7, sizeof(n_ties), hipMemcpyDeviceToHost, ctx->stream));
-                CSC_HIP(hipMemcpyAsync(ctx->conj, d_sorted, nc * sizeof(csc::conj_rec), hipMemcpyDeviceToHost, ctx->stream));
+                if (lazy) {
+                    // The records stay where they are; equal times (rare) are put in (i, j) order on
+                    // the host, so a list with ties comes down after all.
+                    CSC_HIP(hipStreamSynchronize(ctx->stream));
+                    if (n_ties != 0u) {
+                        lazy = false;
+                        if (const int rc = conj_pinned(ctx, h[1])) {
+                            return rc;
+                        }
+                    } else {
+                        ctx->conj_dev = reinterpret_cast<const csc_conjunction *>(d_sorted);
+                        ctx->conj_host_valid = false;
+                    }
+                }
+                if (!lazy) {
+                    CSC_HIP(hipMemcpyAsync(ctx->conj, d_sorted, nc * sizeof(csc::conj_rec), hipMemcpyDeviceToHost, ctx->stream));
+                }
             } else if (h[1]) {
                 CSC_HIP(hipMemcpyAsync(ctx->conj, d_conj, h[1] * sizeof(csc::conj_rec), hipMemcpyDeviceToHost,
                                        ctx->stream));
@@ -2876,7 +2934,7 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
             const auto conj_less = [](const csc_conjunction &a, const csc_conjunction &b) {
                 return std::tie(a.time, a.i, a.j) < std::tie(b.time, b.i, b.j);
             };
-            if (dev_sorted && n_ties == 0u) {
+            if (lazy || (dev_sorted && n_ties == 0u)) {
                 // in time order, all times distinct: nothing left to do
             } else if (dev_sorted) {
                 // Already in time order: only runs of equal times need (i, j) order.
@@ -3080,6 +3138,9 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
     if (coll && !ctx->coll.empty()) {
         std::memcpy(coll, ctx->coll.data(), std::min<uint64_t>(coll_cap, ctx->coll.size()) * sizeof(csc_collision));
     }
+    if (const int rc = conj_materialise(ctx)) {
+        return rc;
+    }
     if (conj && ctx->conj_count) {
         std::memcpy(conj, ctx->conj, std::min<uint64_t>(conj_cap, ctx->conj_count) * sizeof(csc_conjunction));
     }
@@ -3089,10 +3150,84 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
 int csc_narrow_phase_view(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, const csc_conjunction **conj,
                           uint64_t *n_conj)
 {
+    if (const int rc = conj_materialise(ctx)) {
+        return rc;
+    }
     *coll = ctx->coll.data();
     *n_coll = ctx->coll.size();
     *conj = ctx->conj;
     *n_conj = ctx->conj_count;
+    return CSC_OK;
+}
+
+int csc_narrow_phase_lazy(csc_ctx *ctx, int on)
+{
+    ctx->conj_lazy = on != 0;
+    return CSC_OK;
+}
+
+int csc_narrow_phase_counts(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, uint64_t *n_conj, int *conj_on_device)
+{
+    *coll = ctx->coll.data();
+    *n_coll = ctx->coll.size();
+    *n_conj = ctx->conj_count;
+    *conj_on_device = (ctx->conj_dev != nullptr && !ctx->conj_host_valid) ? 1 : 0;
+    return CSC_OK;
+}
+
+int csc_conj_store_append(csc_ctx *ctx, uint64_t count)
+{
+    if (ctx->conj_dev == nullptr || count > ctx->conj_count) {
+        return ctx->invalid("csc_conj_store_append: the last narrow phase left no such records on the device");
+    }
+    if (count == 0u) {
+        return CSC_OK;
+    }
+    CSC_HIP(hipSetDevice(ctx->device));
+    if (ctx->cstore_n + count > ctx->cstore_cap) {
+        const size_t want = std::max<size_t>(2u * ctx->cstore_cap, ctx->cstore_n + count);
+        csc_conjunction *nw = nullptr;
+        CSC_HIP(hipMalloc(reinterpret_cast<void **>(&nw), want * sizeof(csc_conjunction)));
+        if (ctx->cstore_n) {
+            CSC_HIP(hipMemcpyAsync(nw, ctx->cstore, ctx->cstore_n * sizeof(csc_conjunction), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->cstore) {
+            (void)hipFree(ctx->cstore);
+        }
+        ctx->cstore = nw;
+        ctx->cstore_cap = want;
+    }
+    CSC_HIP(hipMemcpyAsync(ctx->cstore + ctx->cstore_n, ctx->conj_dev, count * sizeof(csc_conjunction), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->cstore_n += count;
+    return CSC_OK;
+}
+
+uint64_t csc_conj_store_size(csc_ctx *ctx)
+{
+    return ctx->cstore_n;
+}
+
+int csc_conj_store_download(csc_ctx *ctx, csc_conjunction *dst)
+{
+    if (ctx->cstore_n != 0u) {
+        if (const int rc = csc_download(ctx, dst, ctx->cstore, ctx->cstore_n * sizeof(csc_conjunction), nullptr)) {
+            return rc;
+        }
+    }
+    ctx->cstore_n = 0;
+    return CSC_OK;
+}
+
+int csc_conj_store_reset(csc_ctx *ctx, int release)
+{
+    ctx->cstore_n = 0;
+    if (release && ctx->cstore) {
+        CSC_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->cstore);
+        ctx->cstore = nullptr;
+        ctx->cstore_cap = 0;
+    }
     return CSC_OK;
 }
 

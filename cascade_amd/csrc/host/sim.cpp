@@ -454,6 +454,8 @@ struct sim::sim_data {
     std::vector<conjunction> last_conj;
     const csc_conjunction *last_conj_view = nullptr; // in the context, until the next narrow phase
     std::uint64_t last_conj_n = 0;
+    bool last_conj_on_device = false;  // ... or still on the device (csc_narrow_phase_lazy): fetched on demand
+    std::uint64_t conj_pending = 0;    // records in the context's device-resident store, not yet in m_det_conj
 
     csc_ctx *ctx = nullptr;
     struct dbuf {
@@ -498,6 +500,9 @@ struct sim::sim_data {
                 throw std::runtime_error(std::string("cascade: cannot create the HIP context (there is no CPU fallback): ")
                                          + csc_last_error(nullptr));
             }
+            // Large conjunction lists stay on the device until somebody reads them (CASCADE_CONJ_LAZY=0: off).
+            const char *e = std::getenv("CASCADE_CONJ_LAZY");
+            csc_narrow_phase_lazy(ctx, (e && std::atoi(e) == 0) ? 0 : 1);
         }
     }
     void chk(int rc) const
@@ -580,7 +585,7 @@ sim::sim(const sim &o)
     : m_state(std::make_shared<std::vector<double>>(*o.m_state)), m_pars(std::make_shared<std::vector<double>>(*o.m_pars)),
       m_ct(o.m_ct), m_n_par_ct(o.m_n_par_ct), m_int_info(o.m_int_info), m_reentry_radius(o.m_reentry_radius),
       m_exit_radius(o.m_exit_radius), m_npars(o.m_npars), m_conj_thresh(o.m_conj_thresh),
-      m_det_conj(std::make_shared<std::vector<conjunction>>(*o.m_det_conj)), m_min_coll_radius(o.m_min_coll_radius),
+      m_det_conj(std::make_shared<std::vector<conjunction>>(o.get_conjunctions())), m_min_coll_radius(o.m_min_coll_radius),
       m_coll_whitelist(o.m_coll_whitelist), m_conj_whitelist(o.m_conj_whitelist),
       m_data(std::make_unique<sim_data>(*o.m_data))
 {
@@ -857,6 +862,10 @@ void sim::set_conj_thresh(double v)
 
 void sim::reset_conjunctions()
 {
+    if (m_data->ctx != nullptr && m_data->conj_pending != 0u) {
+        m_data->chk(csc_conj_store_reset(m_data->ctx, 0));
+    }
+    m_data->conj_pending = 0;
     m_det_conj = std::make_shared<std::vector<conjunction>>();
     m_data->conj_segments.clear();
 }
@@ -1015,6 +1024,12 @@ const std::vector<std::tuple<sim::size_type, sim::size_type, double>> &sim::get_
 const std::vector<sim::conjunction> &sim::get_last_step_conjunctions() const
 {
     auto &d = *m_data;
+    if (d.last_conj_on_device && d.ctx != nullptr) {
+        const csc_collision *cp = nullptr;
+        std::uint64_t nc = 0, nj = 0;
+        d.chk(csc_narrow_phase_view(d.ctx, &cp, &nc, &d.last_conj_view, &nj));
+        d.last_conj_on_device = false;
+    }
     if (d.last_conj_view != nullptr) {
         // Copied out of the context on first use.
         d.last_conj.resize(d.last_conj_n);
@@ -1065,6 +1080,31 @@ void sim::download_state()
     }
 }
 
+// The records that supersteps left in the device-resident store (conjunction-heavy runs: 1.75 GB
+// per superstep at 10M objects) join the host vector when somebody looks at it -- a NEW vector when
+// the old one cannot take them, as in append_conj_data below.
+void sim::_sync_conjunctions() const
+{
+    auto &d = *m_data;
+    if (d.conj_pending == 0u || d.ctx == nullptr) {
+        return;
+    }
+    const std::size_t old_n = m_det_conj->size(), n = d.conj_pending;
+    if (old_n + n > m_det_conj->capacity()) {
+        auto nv = std::make_shared<std::vector<conjunction>>();
+        nv->reserve(2u * (old_n + n));
+        prefault(nv->data(), (old_n + n) * sizeof(conjunction));
+        nv->insert(nv->end(), m_det_conj->begin(), m_det_conj->end());
+        m_det_conj = std::move(nv);
+    } else {
+        prefault(m_det_conj->data() + old_n, n * sizeof(conjunction));
+    }
+    m_det_conj->resize(old_n + n);
+    static_assert(sizeof(conjunction) == sizeof(csc_conjunction), "conjunction layout");
+    d.chk(csc_conj_store_download(d.ctx, reinterpret_cast<csc_conjunction *>(m_det_conj->data() + old_n)));
+    d.conj_pending = 0;
+}
+
 // append_conj_data (src/sim_propagate.cpp:1644-1701): the records of this step, sorted by time,
 // go behind the existing ones in a NEW vector (src/sim_narrow_phase.cpp:1000-1011: views of the
 // old one stay valid).
@@ -1072,6 +1112,7 @@ void sim::append_conj_data(const void *recs, std::size_t n)
 {
     static_assert(sizeof(conjunction) == sizeof(csc_conjunction), "conjunction layout");
     const stopwatch sw_append;
+    _sync_conjunctions(); // (earlier supersteps' records come first)
     // src/sim_narrow_phase.cpp:999-1011: when the vector cannot take the new records, a NEW one
     // with twice the needed capacity replaces it (arrays handed out earlier keep the old one
     // alive); otherwise the records are appended in place.
@@ -1228,6 +1269,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     // (the view points into the context's pinned buffer, which the narrow phase below may free)
     d.last_conj_view = nullptr;
     d.last_conj_n = 0;
+    d.last_conj_on_device = false;
     d.last_conj.clear();
     const std::size_t cn = static_cast<std::size_t>(nchunks0) * n;
     double *d_state = d.buf<double>("state", n * 7ull);
@@ -1527,6 +1569,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     const csc_collision *coll_p = nullptr;
     const csc_conjunction *conj_p = nullptr;
     std::uint64_t ncoll_v = 0, nconj_v = 0;
+    bool conj_on_device = false;
     // Everything between the integration and the summary exchange works on THIS process's chunks
     // when the chunks are dealt out, so an error in it is local: it is caught, carried through
     // the exchange as a code, and raised on every process afterwards (a process that threw here
@@ -1647,7 +1690,13 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     // The event lists stay in the context (pinned host memory; a conjunction-heavy superstep
     // yields millions of 128-byte records): no copies besides the append to m_det_conj below.
     if (have_chunks) {
-        d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
+        // (a large conjunction list may have stayed on the device: counts now, records on demand)
+        int on_dev = 0;
+        d.chk(csc_narrow_phase_counts(ctx, &coll_p, &ncoll_v, &nconj_v, &on_dev));
+        conj_on_device = on_dev != 0;
+        if (!conj_on_device) {
+            d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
+        }
     }
     pt.lap("narrow");
     };
@@ -1667,6 +1716,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
             ncoll_v = nconj_v = 0;
             coll_p = nullptr;
             conj_p = nullptr;
+            conj_on_device = false;
         }
     } else {
         local_stages();
@@ -1703,6 +1753,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     d.last_conj.clear();
     d.last_conj_view = conj_p;
     d.last_conj_n = nconj_v;
+    d.last_conj_on_device = conj_on_device;
     std::vector<csc_collision> coll(coll_p, coll_p + ncoll_v);
     std::uint64_t ncand_all = d.stats.np_candidates;
     if (d.shard_n > 1u) {
@@ -1779,7 +1830,18 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         }
         m_int_info.reset();
         pt.lap("final state");
-        if (with_conj) {
+        if (with_conj && conj_on_device) {
+            // The records stay on the device, behind those of the earlier supersteps
+            // (src/sim_propagate.cpp:1644-1701 appends to the host vector: get_conjunctions() does it here).
+            d.chk(csc_conj_store_append(ctx, nconj_v));
+            d.conj_pending += nconj_v;
+            if (nconj_v) {
+                d.conj_segments.emplace_back(d.step_counter, nconj_v);
+            }
+            if (d.conj_pending * sizeof(conjunction) > (24ull << 30)) {
+                _sync_conjunctions(); // (not more than 24 GB of HBM for records nobody has asked for)
+            }
+        } else if (with_conj) {
             append_conj_data(conj_p, nconj_v);
         }
         pt.lap("append conj");
@@ -1791,6 +1853,11 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
             m_int_info = std::array<size_type, 2>{static_cast<size_type>(coll[0].i), static_cast<size_type>(coll[0].j)};
         } else {
             m_int_info = static_cast<size_type>(summ.ste_idx);
+        }
+        if (with_conj && conj_on_device) {
+            d.chk(csc_narrow_phase_view(ctx, &coll_p, &ncoll_v, &conj_p, &nconj_v));
+            d.last_conj_view = conj_p;
+            d.last_conj_on_device = false;
         }
         if (with_conj) {
             // Keep the conjunctions that happen before the interruption (:1329-1336).

@@ -569,45 +569,59 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
                 atomicAdd(q.fuse_cnt + shard * DT_CTR_STRIDE, fill);
                 *fillp = 0u;
             }
-            // (two groups of 64 pairs per trip: the record gathers of both are in flight together)
+            // (two groups of 64 pairs per trip: the record gathers of both are in flight together.)
+            // The survivors are compacted to the front of the buffer -- never ahead of the read
+            // position -- and leave with ONE atomic per flush: with conjunction tracking a twentieth
+            // of the pairs survives, and one atomic per group of 64 on the list's counter is 5e6
+            // same-address atomics per superstep of 10M objects, ~10 ns each, serialised.
+            std::uint32_t nsurv = 0;
             for (std::uint32_t k0 = 0; k0 < fill; k0 += 128u) {
                 bool keep[2];
-                std::uint32_t pa[2], pb[2], c[2];
+                unsigned long long rec[2];
                 float4 ra[2][4], rb[2][4];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const std::uint32_t k = k0 + 64u * g + lane;
                     keep[g] = k < fill;
-                    const unsigned long long rec = buf[keep[g] ? k : k0];
-                    pa[g] = static_cast<std::uint32_t>(rec) & 0xfffffffu;
-                    pb[g] = static_cast<std::uint32_t>(rec >> 28) & 0xfffffffu;
-                    c[g] = static_cast<std::uint32_t>(rec >> 56);
-                    const float4 *qa = q.srecs + (static_cast<std::size_t>(c[g]) * q.n + pa[g]) * 4u;
-                    const float4 *qb = q.srecs + (static_cast<std::size_t>(c[g]) * q.n + pb[g]) * 4u;
+                    rec[g] = buf[keep[g] ? k : k0];
+                    const std::uint32_t pa = static_cast<std::uint32_t>(rec[g]) & 0xfffffffu;
+                    const std::uint32_t pb = static_cast<std::uint32_t>(rec[g] >> 28) & 0xfffffffu;
+                    const std::size_t co = static_cast<std::size_t>(rec[g] >> 56) * q.n;
+                    const float4 *qa = q.srecs + (co + pa) * 4u;
+                    const float4 *qb = q.srecs + (co + pb) * 4u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         ra[g][e] = qa[e];
                         rb[g][e] = qb[e];
                     }
                 }
+                wave_sync(); // (every lane has read its two records of the buffer)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     keep[g] = keep[g] && chord_keep_recs(ra[g], rb[g], q.thr_extra);
                     const unsigned long long km = __ballot(keep[g]);
-                    if (km != 0ull) {
-                        std::uint32_t base = 0;
-                        if (lane == 0) {
-                            base = atomicAdd(q.cand_cnt, static_cast<std::uint32_t>(__popcll(km)));
-                        }
-                        base = __shfl(base, 0);
-                        if (keep[g]) {
-                            const std::uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(static_cast<std::uint32_t>(km >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<std::uint32_t>(km), 0u));
-                            if (slot < q.cand_cap) {
-                                const std::size_t co = static_cast<std::size_t>(c[g]) * q.n;
-                                const std::uint32_t oa = q.vidx[co + pa[g]], ob = q.vidx[co + pb[g]];
-                                q.cand[slot] = make_uint4(oa < ob ? oa : ob, oa < ob ? ob : oa, c[g], 0u);
-                            }
-                        }
+                    if (keep[g]) {
+                        buf[nsurv + __builtin_amdgcn_mbcnt_hi(static_cast<std::uint32_t>(km >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<std::uint32_t>(km), 0u))] = rec[g];
+                    }
+                    nsurv += static_cast<std::uint32_t>(__popcll(km));
+                }
+            }
+            wave_sync();
+            if (nsurv != 0u) {
+                std::uint32_t base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(q.cand_cnt, nsurv);
+                }
+                base = __shfl(base, 0);
+                for (std::uint32_t k = lane; k < nsurv; k += 64u) {
+                    if (base + k < q.cand_cap) {
+                        const unsigned long long rec = buf[k];
+                        const std::uint32_t pa = static_cast<std::uint32_t>(rec) & 0xfffffffu;
+                        const std::uint32_t pb = static_cast<std::uint32_t>(rec >> 28) & 0xfffffffu;
+                        const std::uint32_t c = static_cast<std::uint32_t>(rec >> 56);
+                        const std::size_t co = static_cast<std::size_t>(c) * q.n;
+                        const std::uint32_t oa = q.vidx[co + pa], ob = q.vidx[co + pb];
+                        q.cand[base + k] = make_uint4(oa < ob ? oa : ob, oa < ob ? ob : oa, c, 0u);
                     }
                 }
             }

@@ -231,7 +231,7 @@ private:
     double m_exit_radius = 0;
     std::uint32_t m_npars = 0;
     double m_conj_thresh = 0;
-    std::shared_ptr<std::vector<conjunction>> m_det_conj;
+    mutable std::shared_ptr<std::vector<conjunction>> m_det_conj;
     double m_min_coll_radius = 0;
     whitelist_t m_coll_whitelist, m_conj_whitelist;
     std::unique_ptr<sim_data> m_data;
@@ -324,8 +324,11 @@ public:
         return m_conj_thresh;
     }
     void set_conj_thresh(double);
+    // (This build keeps the records of conjunction-heavy supersteps on the device and brings them
+    // to the host vector when somebody looks: _sync_conjunctions().)
     [[nodiscard]] const std::vector<conjunction> &get_conjunctions() const
     {
+        _sync_conjunctions();
         return *m_det_conj;
     }
     void reset_conjunctions();
@@ -361,8 +364,10 @@ public:
     }
     [[nodiscard]] std::shared_ptr<std::vector<conjunction>> _get_conjunctions_ptr() const
     {
+        _sync_conjunctions();
         return m_det_conj;
     }
+    void _sync_conjunctions() const;
 
     // ---- additions of this build (not in the reference) -------------------------------
     [[nodiscard]] const dynamics::dyn_t &get_dyn() const;

@@ -402,6 +402,24 @@ int csc_narrow_phase_get(csc_ctx *ctx, csc_collision *coll, uint64_t coll_cap, c
 int csc_narrow_phase_view(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, const csc_conjunction **conj,
                           uint64_t *n_conj);
 
+/* Conjunction-heavy supersteps (10M objects in shells: 1.4e7 records = 1.75 GB per superstep) are
+ * bound by what happens to the records on the way out (src/sim_narrow_phase.cpp:985-1011,
+ * src/sim_propagate.cpp:1644-1701 append them to a host vector). Lazy mode: a list that was sorted
+ * on the device (more than 32768 records, no two with the same time) stays there;
+ * csc_narrow_phase_view / _get fetch the host copy when somebody asks. csc_narrow_phase_counts gives
+ * the collisions and the number of conjunctions without fetching anything. csc_conj_store_append
+ * adds the first `count` records of that device list to a device-resident store that grows by
+ * doubling; csc_conj_store_download copies the whole store to `dst` (pageable memory is fine:
+ * pipelined like csc_download) and empties it; csc_conj_store_reset empties (and optionally
+ * frees) it. cascade::sim keeps the conjunctions of successive steps there and materialises
+ * get_conjunctions() on access. */
+int csc_narrow_phase_lazy(csc_ctx *ctx, int on);
+int csc_narrow_phase_counts(csc_ctx *ctx, const csc_collision **coll, uint64_t *n_coll, uint64_t *n_conj, int *conj_on_device);
+int csc_conj_store_append(csc_ctx *ctx, uint64_t count);
+uint64_t csc_conj_store_size(csc_ctx *ctx);
+int csc_conj_store_download(csc_ctx *ctx, csc_conjunction *dst);
+int csc_conj_store_reset(csc_ctx *ctx, int release);
+
 /* ---- propagation sharded over GPUs ("particles are sharded for propagation, chunk
  * AABBs and Morton codes are gathered with RCCL all-gather") -------------------------------
  * No counterpart in the reference, which is single-process. csc_propagate_range is csc_propagate
