@@ -447,6 +447,7 @@ struct sim::sim_data {
     std::uint64_t state_hash[2] = {0, 0}, pars_hash[2] = {0, 0};
     bool hash_valid = false;
     bool wave_env = true, fuse_env = true; // CASCADE_WAVE / CASCADE_BP_FUSE != 0
+    bool verify = false;                  // CASCADE_VERIFY=1: the reference's debug verifiers after every stage
     std::uint64_t step_counter = 0; // step() calls so far (identical on the processes of a sharded simulation)
     std::vector<std::pair<std::uint64_t, std::uint64_t>> conj_segments;
     step_stats stats;
@@ -471,7 +472,7 @@ struct sim::sim_data {
           device(o.device), time(o.time), host_sync(o.host_sync), np_prefilter(o.np_prefilter),
           single_pass_mode(o.single_pass_mode),
           shard_rank(o.shard_rank), shard_n(o.shard_n), exchange(o.exchange), gather(o.gather), shard_chunks(o.shard_chunks), alltoall(o.alltoall),
-          wave_env(o.wave_env), fuse_env(o.fuse_env)
+          wave_env(o.wave_env), fuse_env(o.fuse_env), verify(o.verify)
     {
     }
     ~sim_data()
@@ -716,6 +717,7 @@ void sim::finalise_ctor(options o)
     // (measurement / test switches, read when the simulation is constructed)
     m_data->wave_env = !(std::getenv("CASCADE_WAVE") && std::atoi(std::getenv("CASCADE_WAVE")) == 0);
     m_data->fuse_env = !(std::getenv("CASCADE_BP_FUSE") && std::atoi(std::getenv("CASCADE_BP_FUSE")) == 0);
+    m_data->verify = std::getenv("CASCADE_VERIFY") && std::atoi(std::getenv("CASCADE_VERIFY")) != 0;
 
     verify_state_vector(*m_state);
 }
@@ -1176,6 +1178,198 @@ void sim::dense_propagate(double t)
     }
 }
 
+// ---- CASCADE_VERIFY=1 ------------------------------------------------------------------------
+// The reference runs three verifiers inside step() in its debug builds: verify_global_aabbs
+// (src/sim_propagate.cpp:1348-1380), verify_bvh_trees_parallel (src/sim_bvh.cpp:498-656) and
+// verify_broad_phase_parallel (src/sim_broad_phase.cpp:221-321, up to 10 000 particles). Here they
+// are a run-time mode of the product: the device outputs of every stage of a step() come back to
+// the host and go through the same checks; a violation throws std::logic_error. Slow by design.
+namespace
+{
+
+void vfail(const std::string &what)
+{
+    throw std::logic_error("CASCADE_VERIFY: " + what);
+}
+
+template <typename T>
+std::vector<T> vfetch(csc_ctx *ctx, const T *d_src, std::size_t count)
+{
+    std::vector<T> v(count);
+    if (count != 0u && csc_memcpy_d2h(ctx, v.data(), d_src, count * sizeof(T)) != CSC_OK) {
+        vfail(std::string("cannot read back a device array: ") + csc_last_error(ctx));
+    }
+    return v;
+}
+
+struct verify_arrays {
+    std::vector<float> lbs, ubs; // [C][n][4]
+    std::vector<std::uint32_t> vidx;
+};
+
+// Global boxes, Morton order, sorted arrays and the trees of the chunks [0, cl).
+verify_arrays verify_sort_and_trees(csc_ctx *ctx, std::uint32_t n, std::uint32_t cl, const float *d_lbs, const float *d_ubs,
+                                    const float *d_glb, const float *d_gub, const std::uint64_t *d_codes, const std::uint32_t *d_vidx,
+                                    const std::uint64_t *d_scodes, const float *d_slbs, const float *d_subs)
+{
+    const std::size_t cn = static_cast<std::size_t>(cl) * n;
+    verify_arrays va{vfetch(ctx, d_lbs, cn * 4u), vfetch(ctx, d_ubs, cn * 4u), vfetch(ctx, d_vidx, cn)};
+    const auto glb = vfetch(ctx, d_glb, cl * 4ull), gub = vfetch(ctx, d_gub, cl * 4ull);
+    const auto codes = vfetch(ctx, d_codes, cn), scodes = vfetch(ctx, d_scodes, cn);
+    const auto slbs = vfetch(ctx, d_slbs, cn * 4u), subs = vfetch(ctx, d_subs, cn * 4u);
+    const float finf = std::numeric_limits<float>::infinity();
+    std::vector<csc_bvh_node> tree(2ull * n);
+    void *d_nodes = nullptr;
+    if (csc_malloc(ctx, tree.size() * sizeof(csc_bvh_node), &d_nodes) != CSC_OK) {
+        vfail("cannot allocate the tree export buffer");
+    }
+    struct free_nodes {
+        csc_ctx *c;
+        void *p;
+        ~free_nodes()
+        {
+            csc_free(c, p);
+        }
+    } guard{ctx, d_nodes};
+    for (std::uint32_t c = 0; c < cl; ++c) {
+        const std::string at = " (chunk " + std::to_string(c) + ")";
+        const float *lb = va.lbs.data() + static_cast<std::size_t>(c) * n * 4u, *ub = va.ubs.data() + static_cast<std::size_t>(c) * n * 4u;
+        // verify_global_aabbs: exact equality with the serial minimum / maximum. (The upper bound is
+        // checked before disc_single_coord's in-place nextafter, src/sim_propagate.cpp:448-449:
+        // csc_morton_encode leaves the stored value alone.)
+        float mn[4] = {finf, finf, finf, finf}, mx[4] = {-finf, -finf, -finf, -finf};
+        for (std::uint32_t i = 0; i < n; ++i) {
+            for (int j = 0; j < 4; ++j) {
+                mn[j] = std::min(mn[j], lb[i * 4u + j]);
+                mx[j] = std::max(mx[j], ub[i * 4u + j]);
+            }
+        }
+        for (int j = 0; j < 4; ++j) {
+            if (mn[j] != glb[c * 4u + j] || mx[j] != gub[c * 4u + j]) {
+                vfail("the global AABB differs from the serial minimum / maximum" + at);
+            }
+        }
+        // Sorted codes and gathered boxes (assert(is_sorted), src/sim_propagate.cpp:506; :493-504).
+        const std::uint64_t *sc = scodes.data() + static_cast<std::size_t>(c) * n, *mc = codes.data() + static_cast<std::size_t>(c) * n;
+        const std::uint32_t *vx = va.vidx.data() + static_cast<std::size_t>(c) * n;
+        const float *slb = slbs.data() + static_cast<std::size_t>(c) * n * 4u, *sub = subs.data() + static_cast<std::size_t>(c) * n * 4u;
+        std::vector<char> seen(n, 0);
+        for (std::uint32_t k = 0; k < n; ++k) {
+            if (vx[k] >= n || seen[vx[k]]) {
+                vfail("the sort did not produce a permutation" + at);
+            }
+            seen[vx[k]] = 1;
+            if ((k != 0u && sc[k] < sc[k - 1u]) || sc[k] != mc[vx[k]]) {
+                vfail("the Morton codes are not sorted, or not those of the permuted particles" + at);
+            }
+            if (std::memcmp(slb + k * 4u, lb + vx[k] * 4u, 16) != 0 || std::memcmp(sub + k * 4u, ub + vx[k] * 4u, 16) != 0) {
+                vfail("a sorted box is not the box of the permuted particle" + at);
+            }
+        }
+        // verify_bvh_trees_parallel.
+        std::uint64_t nn = 0;
+        if (csc_bvh_export(ctx, c, static_cast<csc_bvh_node *>(d_nodes), tree.size(), &nn) != CSC_OK
+            || csc_memcpy_d2h(ctx, tree.data(), d_nodes, nn * sizeof(csc_bvh_node)) != CSC_OK) {
+            vfail(std::string("cannot export the tree: ") + csc_last_error(ctx) + at);
+        }
+        std::vector<char> pset(n, 0);
+        for (std::uint64_t i = 0; i < nn; ++i) {
+            const csc_bvh_node &nd = tree[i];
+            bool ok = nd.end > nd.begin && nd.end <= n && (nd.left == -1) == (nd.right == -1);
+            if (ok && nd.left == -1) {
+                for (std::uint32_t j = nd.begin; j < nd.end && ok; ++j) {
+                    ok = sc[j] == sc[nd.begin] && !pset[j];
+                    pset[j] = 1;
+                }
+                ok = ok && nd.split_idx <= 64;
+            } else if (ok) {
+                const auto ul = static_cast<std::uint64_t>(nd.left), ur = static_cast<std::uint64_t>(nd.right);
+                ok = nd.left > 0 && nd.right > 0 && ul > i && ul < nn && ur > i && ur < nn && tree[ul].begin == nd.begin && tree[ul].end < nd.end
+                     && tree[ur].begin == tree[ul].end && tree[ur].end == nd.end && nd.split_idx <= 63;
+                if (ok) {
+                    const std::uint32_t sp = tree[ul].end - 1u;
+                    // (first_diff_bit, src/sim_bvh.cpp:59-80: the children differ first at bit split_idx from the top)
+                    ok = sp + 1u < n && sc[sp] != sc[sp + 1u] && __builtin_clzll(sc[sp] ^ sc[sp + 1u]) == nd.split_idx;
+                }
+            }
+            if (ok && i == 0u) {
+                ok = nd.parent == -1 && nd.begin == 0u && nd.end == n;
+            } else if (ok) {
+                const auto up = static_cast<std::uint64_t>(nd.parent);
+                ok = nd.parent >= 0 && up < i && nd.begin >= tree[up].begin && nd.end <= tree[up].end
+                     && (nd.begin == tree[up].begin || nd.end == tree[up].end);
+            }
+            ok = ok && nd.nn_level > 0u;
+            if (ok) {
+                float l4[4] = {finf, finf, finf, finf}, u4[4] = {-finf, -finf, -finf, -finf};
+                for (std::uint32_t j = nd.begin; j < nd.end; ++j) {
+                    for (int k = 0; k < 4; ++k) {
+                        l4[k] = std::min(l4[k], slb[j * 4u + k]);
+                        u4[k] = std::max(u4[k], sub[j * 4u + k]);
+                    }
+                }
+                ok = std::memcmp(l4, nd.lb, 16) == 0 && std::memcmp(u4, nd.ub, 16) == 0;
+            }
+            if (!ok) {
+                vfail("node " + std::to_string(i) + " of the BVH violates the tree invariants" + at);
+            }
+        }
+        for (std::uint32_t j = 0; j < n; ++j) {
+            if (!pset[j]) {
+                vfail("a particle belongs to no leaf of the BVH" + at);
+            }
+        }
+    }
+    return va;
+}
+
+// verify_broad_phase_parallel: pairs unique with i < j; every overlapping, active pair present.
+void verify_pairs(csc_ctx *ctx, std::uint32_t n, std::uint32_t cl, const verify_arrays &va, const std::uint8_t *d_active, std::uint64_t npairs)
+{
+    if (n > 10000u) {
+        return;
+    }
+    const auto active = vfetch(ctx, d_active, n);
+    std::vector<std::uint32_t> pairs(std::max<std::uint64_t>(npairs, 1) * 2u);
+    std::uint64_t total = 0;
+    for (std::uint32_t c = 0; c < cl; ++c) {
+        const std::string at = " (chunk " + std::to_string(c) + ")";
+        std::uint64_t cnt = 0;
+        if (csc_broad_phase_get(ctx, c, pairs.data(), npairs, &cnt) != CSC_OK || cnt > npairs) {
+            vfail(std::string("cannot read the pair list: ") + csc_last_error(ctx) + at);
+        }
+        total += cnt;
+        std::vector<std::uint64_t> keys(cnt);
+        for (std::uint64_t k = 0; k < cnt; ++k) {
+            if (pairs[2u * k] >= pairs[2u * k + 1u] || pairs[2u * k + 1u] >= n) {
+                vfail("a broad-phase pair is not (i < j)" + at);
+            }
+            keys[k] = static_cast<std::uint64_t>(pairs[2u * k]) << 32 | pairs[2u * k + 1u];
+        }
+        std::sort(keys.begin(), keys.end());
+        if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) {
+            vfail("a broad-phase pair is listed twice" + at);
+        }
+        const float *lb = va.lbs.data() + static_cast<std::size_t>(c) * n * 4u, *ub = va.ubs.data() + static_cast<std::size_t>(c) * n * 4u;
+        for (std::uint32_t i = 0; i < n; ++i) {
+            for (std::uint32_t j = i + 1u; j < n; ++j) {
+                bool ov = (active[i] | active[j]) != 0;
+                for (int k = 0; k < 4 && ov; ++k) {
+                    ov = ub[i * 4u + k] >= lb[j * 4u + k] && lb[i * 4u + k] <= ub[j * 4u + k];
+                }
+                if (ov && !std::binary_search(keys.begin(), keys.end(), static_cast<std::uint64_t>(i) << 32 | j)) {
+                    vfail("the overlapping pair (" + std::to_string(i) + ", " + std::to_string(j) + ") is missing from the broad phase" + at);
+                }
+            }
+        }
+    }
+    if (total != npairs) {
+        vfail("the per-chunk pair lists do not add up to the reported count");
+    }
+}
+
+} // namespace
+
 // step(): src/sim_propagate.cpp:516-1345.
 outcome sim::step()
 {
@@ -1593,6 +1787,10 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     if (have_chunks) {
         d.chk(csc_bvh_build(ctx, n, cl, d_scodes, d_slbs, d_subs));
     }
+    verify_arrays vdata;
+    if (d.verify && have_chunks) {
+        vdata = verify_sort_and_trees(ctx, n, cl, d_lbs, d_ubs, d_glb, d_gub, d_codes, d_vidx, d_scodes, d_slbs, d_subs);
+    }
     if (tracing) {
         d.chk(csc_sync(ctx));
         log_line(LOG_TRACE, "BVH construction time: " + sw.elapsed() + "s");
@@ -1605,12 +1803,15 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     // With the pre-filter on, the box-overlap pairs are counted and filtered inside the tile kernel
     // of the traversal and only the candidates of the polynomial test are stored (csc_broad_phase_filtered).
-    const bool fused = have_chunks && d.np_prefilter && d_srecs != nullptr && d.fuse_env;
+    const bool fused = have_chunks && d.np_prefilter && d_srecs != nullptr && d.fuse_env && !d.verify; // (the verifier wants the pair list)
     if (fused) {
         std::uint64_t ncand = 0;
         d.chk(csc_broad_phase_filtered(ctx, n, cl, d_slbs, d_subs, d_vidx, d_active, m_conj_thresh, d_srecs, &npairs, &ncand));
     } else if (have_chunks) {
         d.chk(csc_broad_phase(ctx, n, cl, d_slbs, d_subs, d_vidx, d_active, &npairs));
+        if (d.verify) {
+            verify_pairs(ctx, n, cl, vdata, d_active, npairs);
+        }
     }
     if (tracing) {
         // src/sim_broad_phase.cpp:209-213 (with a sharded simulation: this process's share)

@@ -688,3 +688,35 @@ def test_trace_log_lines(capfd):
     assert m and abs(float(m.group(1)) - s.last_bp_pairs / 2 / 5000) < 1e-9
     s.step()
     assert "[cascade]" not in capfd.readouterr().out, "silent at the default level"
+
+
+@pytest.mark.gpu
+def test_verify_mode_runs_the_reference_verifiers(monkeypatch):
+    """CASCADE_VERIFY=1: the reference's debug verifiers (src/sim_propagate.cpp:1348-1380,
+    src/sim_bvh.cpp:498-656, src/sim_broad_phase.cpp:221-321) on the device outputs of every stage
+    of step(): silent on correct runs (same results as without), for chunked and unchunked
+    supersteps, equal Morton codes (multi-particle leaves) and conjunction tracking."""
+    from cascade_amd import sim
+    from cascade_amd.workloads import random_leo_pop_kep
+
+    st = random_leo_pop_kep(3000, seed=6)
+    st[:, 6] *= 3e3
+    st[7] = st[3]  # two particles with the same trajectory: equal Morton codes in every chunk
+    st[7, 6] = 0.0
+    st[3, 6] = 0.0
+    for n_par_ct in (1, 3):
+        kw = dict(n_par_ct=n_par_ct, conj_thresh=2e-3)
+        monkeypatch.delenv("CASCADE_VERIFY", raising=False)
+        a = sim(st.copy(), 0.23, **kw)
+        monkeypatch.setenv("CASCADE_VERIFY", "1")
+        b = sim(st.copy(), 0.23, **kw)
+        for _ in range(3):
+            assert a.step() == b.step()
+            assert np.array_equal(a.state, b.state) and a.last_bp_pairs == b.last_bp_pairs
+            assert a.conjunctions.tobytes() == b.conjunctions.tobytes()
+    # A non-finite box is the reference's ValueError before any verifier looks.
+    bad = st.copy()
+    bad[0, :3] = 1e39
+    s = sim(bad, 0.23)
+    with pytest.raises(ValueError):
+        s.step()
