@@ -40,6 +40,27 @@ def test_noalloc_global_aabb_matches_allocating_entry_point():
             rl, ru, gl, gu = ref_lb.download(), ref_ub.download(), got_lb.download(), got_ub.download()
             assert rl.tobytes() == gl.tobytes() and ru.tobytes() == gu.tobytes(), (nchunks, n)
             assert np.array_equal(gl, lbs.min(axis=1)) and np.array_equal(gu, ubs.max(axis=1))
+        # The property the entry point exists for: it allocates nothing. Free device memory (as
+        # the HIP runtime reports it) is the same before and after a series of calls, while a first
+        # call of the allocating entry point on a fresh size does take memory.
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+        def free_bytes():
+            fr, tot = C.c_size_t(), C.c_size_t()
+            assert hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+            return fr.value
+
+        lbs, ubs = _boxes(rng, 4, 2_000_000)  # (larger than anything the context has seen so far)
+        d_lbs, d_ubs = ctx.array(lbs), ctx.array(ubs)
+        got_lb, got_ub = ctx.empty((4, 4), np.float32), ctx.empty((4, 4), np.float32)
+        chk(L.csc_sync(h))
+        before = free_bytes()
+        for _ in range(3):
+            chk(L.csc_global_aabb_noalloc(h, 2_000_000, 4, d_lbs.ptr, d_ubs.ptr, got_lb.ptr, got_ub.ptr))
+        chk(L.csc_sync(h))
+        assert free_bytes() == before, "csc_global_aabb_noalloc took device memory"
+        assert np.array_equal(got_lb.download(), lbs.min(axis=1)) and np.array_equal(got_ub.download(), ubs.max(axis=1))
         # Beyond the maximum: a clear error, nothing launched.
         mx = int(L.csc_global_aabb_noalloc_max_chunks())
         assert mx == 32768
