@@ -103,7 +103,6 @@ struct csc_ctx {
     uint64_t bp_tiles = 0; // tiles of the last dual traversal
     uint64_t bp_node_pairs = 0;
     int bp_mode = -1; // -1: read CASCADE_BP_MODE once; 0 per-particle walks, 1 dual traversal
-    int box_kernel = -1; // -1: read CASCADE_BOX_KERNEL once; 1: boxes of a pass with rows by k_chunk_boxes
     unsigned long long *d_bp_counter = nullptr;
     // narrow phase results (host copies)
     std::vector<csc_collision> coll;
@@ -1432,10 +1431,6 @@ static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, con
     dim3 grid(cdiv(n, 64)), block(64);
     // With rows: the boxes and samples come from the rows, in a kernel of their own (order 20,
     // built-in dynamics; CASCADE_BOX_KERNEL=0: fused into the integration as without rows).
-    if (ctx->box_kernel < 0) {
-        const char *e = std::getenv("CASCADE_BOX_KERNEL");
-        ctx->box_kernel = (e && std::atoi(e) == 0) ? 0 : 1;
-    }
     // (k_propagate_wave whenever the pass writes rows and the dynamics come with their tape)
     bool waved = false;
     if (row_cap != 0u) {
@@ -1445,7 +1440,7 @@ static int propagate_impl(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, con
     }
     ctx->pass1_wave = waved;
     const int wave_ng = waved ? 1 : 0;
-    const bool nobox = wave_ng != 0 || (row_cap != 0u && ctx->box_kernel == 1 && cfg->order == 20u && cfg->dyn_kind != CSC_DYN_TAPE);
+    const bool nobox = wave_ng != 0 || (row_cap != 0u && cfg->order == 20u && cfg->dyn_kind != CSC_DYN_TAPE);
     if (wave_ng == 0) {
         if (cfg->dyn_kind == CSC_DYN_TAPE) {
             if (const int rc = bind_tape(ctx, cfg, n, p, grid)) {
@@ -1837,33 +1832,20 @@ int csc_morton_encode(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const float *d
 static int radix_sort(csc_ctx *ctx, uint32_t n, uint32_t nseg, int nbits, uint64_t *keys_a, uint32_t *vals_a,
                       bool vals_iota, uint64_t *keys_b, uint32_t *vals_b, uint64_t **keys_res, uint32_t **vals_res)
 {
-    // 2048 keys per block; 8192 was measured and is slower even at 8M keys
-    // (scatter 2.86 against 2.00 ms per 8 passes: the ranking chain of a wave is four times as
-    // long and fewer waves hide it; the writes were not the limit).
-    const char *ei = std::getenv("CASCADE_RS_ITEMS");
-    const bool big = ei && std::atoi(ei) >= csc::RS_ITEMS_BIG;
-    const unsigned nblocks = cdiv(n, csc::RS_BLOCK * (big ? csc::RS_ITEMS_BIG : csc::RS_ITEMS));
+    // 2048 keys per block (8192 was measured in round 2 and is slower even at 8M keys: the ranking
+    // chain of a wave is four times as long and fewer waves hide it).
+    const unsigned nblocks = cdiv(n, csc::RS_BLOCK * csc::RS_ITEMS);
     CSC_BUF(d_hist, uint32_t, "rs_hist", static_cast<size_t>(nseg) * csc::RS_BINS * nblocks);
     CSC_BUF(d_btot, uint32_t, "rs_bin_tot", static_cast<size_t>(nseg) * csc::RS_BINS);
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
     bool iota = vals_iota;
     for (int shift = 0; shift < nbits; shift += 8) {
-        if (big) {
-            KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist<csc::RS_ITEMS_BIG>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream,
-                                                kin, n, shift, d_hist, nblocks));
-        } else {
-            KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist<csc::RS_ITEMS>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
-                                                n, shift, d_hist, nblocks));
-        }
+        KT("k_rs_hist", hipLaunchKernelGGL(csc::k_rs_hist<csc::RS_ITEMS>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream, kin,
+                                            n, shift, d_hist, nblocks));
         KT("k_rs_scan", hipLaunchKernelGGL(csc::k_rs_scan, dim3(csc::RS_BINS, nseg), dim3(256), 0, ctx->stream, d_hist, nblocks, d_btot));
-        if (big) {
-            KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter<csc::RS_ITEMS_BIG>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0,
-                                                   ctx->stream, kin, iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
-        } else {
-            KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter<csc::RS_ITEMS>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream,
-                                                   kin, iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
-        }
+        KT("k_rs_scatter", hipLaunchKernelGGL(csc::k_rs_scatter<csc::RS_ITEMS>, dim3(nblocks, nseg), dim3(csc::RS_BLOCK), 0, ctx->stream,
+                                               kin, iota ? nullptr : vin, kout, vout, n, shift, d_hist, nblocks, d_btot));
         CSC_LAUNCH_CHECK();
         std::swap(kin, kout);
         std::swap(vin, vout);
@@ -1987,11 +1969,10 @@ static int bvh_build_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const uint
         KT("k_bvh_emit", hipLaunchKernelGGL(csc::k_bvh_emit_fast, gn, blk, 0, ctx->stream, b));
     }
     // Bottom-up refit (arrival counters start from zero): the subtrees inside a workgroup's leaves
-    // first (Karras numbering only), then one launch across workgroups. CASCADE_BVH_REFIT=global:
-    // the second kernel alone, from the leaves (measurements).
+    // first (Karras numbering only), then one launch across workgroups (the reference's node
+    // order: the second kernel alone, from the leaves).
     CSC_HIP(hipMemsetAsync(b.visit, 0, cnn * sizeof(uint32_t), ctx->stream));
-    const char *er = std::getenv("CASCADE_BVH_REFIT");
-    const bool local_first = !canonical && !(er && std::string(er) == "global");
+    const bool local_first = !canonical;
     if (local_first) {
         KT("k_bvh_refit_local", hipLaunchKernelGGL(csc::k_bvh_refit_local, gp, blk, 0, ctx->stream, b));
     }
@@ -2103,9 +2084,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
     // with 64 x 256 threads, 1.47 with 256 x 256, 1.42 with 512 x 128, 1.45 with 1024 x 128, 1.47
     // with 1024 x 64: more, smaller workgroups balance the load and hide the gather latency better
     // until the empty ones of the small levels cost more); 128 for small populations.
-    // CASCADE_DT_GRID overrides (measurements).
-    const unsigned per_shard = std::getenv("CASCADE_DT_GRID") ? std::max(1, std::atoi(std::getenv("CASCADE_DT_GRID")))
-                                                              : (static_cast<uint64_t>(n) * nchunks >= 200000u ? 16384u / DT_SHARDS : 4096u / DT_SHARDS);
+    const unsigned per_shard = static_cast<uint64_t>(n) * nchunks >= 200000u ? 16384u / DT_SHARDS : 4096u / DT_SHARDS;
     const unsigned grid = DT_SHARDS * per_shard;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -2171,14 +2150,10 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
             }
             // Workgroups stride over the tile batches of their shard: 8 per CU fill the chip.
             const unsigned tg = static_cast<uint64_t>(n) * nchunks >= 200000u ? 2048u : 256u;
-            if (fuse && tile_max <= 8u) {
+            if (fuse) {
                 KT("k_bp_tiles", hipLaunchKernelGGL((k_bp_tiles<8, true>), dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
-            } else if (fuse) {
-                KT("k_bp_tiles", hipLaunchKernelGGL((k_bp_tiles<16, true>), dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
-            } else if (tile_max <= 8u) {
-                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
             } else {
-                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<16>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
+                KT("k_bp_tiles", hipLaunchKernelGGL(k_bp_tiles<8>, dim3(tg), dim3(64 * DT_TILE_WAVES), 0, ctx->stream, q));
             }
         };
         bool tiles_launched = false;
@@ -2198,7 +2173,7 @@ static int broad_phase_dual(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
                 // (16384 workgroups that find nothing to do cost 6 us per level, and half of the
                 // ~32 levels hold a few thousand items.)
                 unsigned g = grid;
-                if (static_cast<size_t>(level) < ctx->dt_level_items.size() && !std::getenv("CASCADE_DT_GRID")) {
+                if (static_cast<size_t>(level) < ctx->dt_level_items.size()) {
                     const uint64_t want = cdiv(ctx->dt_level_items[level] * 3u / 2u + 1u, static_cast<uint64_t>(DT_SHARDS) * DT_BLOCK);
                     g = DT_SHARDS * static_cast<unsigned>(std::min<uint64_t>(std::max<uint64_t>(want, 1u), per_shard));
                 }
@@ -2387,8 +2362,8 @@ static int broad_phase_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, const fl
     const bool dual = ctx->bp_mode == 1 && ctx->bvh.nn_max < csc::DT_MAX_NODES && nchunks <= csc::DT_MAX_CHUNKS;
     uint32_t tile_max = 0;
     if (dual && n < csc::DT_TILE_MAX_N) {
-        const char *e = std::getenv("CASCADE_DT_TILE");
-        tile_max = e ? std::min<uint32_t>(static_cast<uint32_t>(std::max(0, std::atoi(e))), csc::DT_TILE_LIMIT) : 8u;
+        const char *e = std::getenv("CASCADE_DT_TILE"); // (0: the traversal down to the leaves; tests)
+        tile_max = (e && std::atoi(e) == 0) ? 0u : 8u;
     }
     uint32_t *d_sinfo = nullptr, *d_sleaf = nullptr;
     CSC_BUF(d_multi, uint32_t, "bvh_multi_flag", 1);
@@ -2781,12 +2756,9 @@ static int narrow_impl(csc_ctx *ctx, uint32_t n, uint32_t nchunks, double ct, do
                 flat_tiles += cdiv(src.flat_cnt[s], csc::NP_FLAT_TILE);
             }
             q.flat_tile_off[csc::NP_FLAT_SHARDS] = flat_tiles;
-            {
-                // Runs of 256 consecutive workgroups (of 1024 pairs) per XCD (measured with workgroups of 256 pairs at 1M objects x 8 chunks:
-                // 4.46 ms in dispatch order, 4.41 / 4.31 / 4.33 with runs of 64 / 1024 / 16384).
-                const char *e = std::getenv("CASCADE_NP_XCD_RUN");
-                q.flat_xcd_run = e ? static_cast<uint32_t>(std::max(0, std::atoi(e))) : 256u;
-            }
+            // Runs of 256 consecutive workgroups (of 1024 pairs) per XCD (measured in round 2: 4.46 ms in
+            // dispatch order, 4.41 / 4.31 / 4.33 with runs of 64 / 1024 / 16384).
+            q.flat_xcd_run = 256u;
         }
         q.srt_recs = reinterpret_cast<const float4 *>(src.srt_recs);
         q.cand = src.cand ? const_cast<uint4 *>(src.cand) : d_cand;

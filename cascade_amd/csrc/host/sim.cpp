@@ -2005,7 +2005,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
         }
     }
     // (the same decision on every process: ncand_all is the global count)
-    static const std::uint64_t sparse_factor = std::getenv("CASCADE_SPARSE_FACTOR") ? std::max(0, std::atoi(std::getenv("CASCADE_SPARSE_FACTOR"))) : 8;
+    constexpr std::uint64_t sparse_factor = 8;
     d.sparse_likely = ncand_all * sparse_factor <= n;
 
     // Outcome resolution (:1189-1345). coll is sorted by (time, i, j); a collision wins a tie

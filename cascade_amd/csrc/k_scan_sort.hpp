@@ -144,10 +144,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const std::uint32_t *
 // ---------------------------------------------------------------------------
 constexpr int RS_BLOCK = 256;
 constexpr int RS_WAVES = RS_BLOCK / 64;
-// Keys per thread: 8 (2048 per block). 32 (8192 per block: a quarter of the per-block counters,
-// is kept for measurements only (CASCADE_RS_ITEMS=16): 8192 per block was slower at 1M and 8M keys.
+// Keys per thread: 8 (2048 per block; 8192 per block was slower at 1M and 8M keys).
 constexpr int RS_ITEMS = 8;
-constexpr int RS_ITEMS_BIG = 16;
 constexpr int RS_BINS = 256;
 
 // block_hist layout: [chunk][bin][nblocks] (so that one linear exclusive scan per chunk
