@@ -3,6 +3,7 @@
 // Translation unit of k_propagate_wave (one object over 8 to 64 lanes, series in LDS): the
 // scheduler that turns a dynamics tape into rows of independent operations, and the launcher.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -248,6 +249,18 @@ void wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
         }
     }
     out.nrows = rows;
+    if (std::getenv("CASCADE_WAVE_DEBUG")) {
+        // operations per dependency level, by kind: s = with a convolution sum, l = linear only
+        for (int lv = 1; lv <= max_level; ++lv) {
+            int ns = 0, nl = 0;
+            for (std::size_t k = 0; k < items.size(); ++k) {
+                if (lvl[k] == lv) {
+                    ((items[k].w.f >> 24) & WF_SUM) ? ++ns : ++nl;
+                }
+            }
+            std::fprintf(stderr, "[wave] level %2d: %2d sums, %2d linear\n", lv, ns, nl);
+        }
+    }
     const std::uint32_t L = order + 1u;
     out.obj_doubles = ((nslots + 1u) * L + rows * static_cast<std::uint32_t>(ng) + L + 1u) & ~1u;
     for (int c = 0; c < 7; ++c) {

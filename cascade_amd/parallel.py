@@ -142,6 +142,17 @@ def shard(sim_obj, group=None, propagation=True, chunks=True, alltoall=True):
     return sim_obj
 
 
+def make_event_exchange(*_a, **_k):
+    """Removed in round 2 (the conjunction records no longer travel during the run)."""
+    raise RuntimeError("cascade_amd.parallel.make_event_exchange is gone: shard(sim) sets up make_summary_exchange(); "
+                       "read the merged conjunction list with gather_conjunctions(sim)")
+
+
+def merge_events(*_a, **_k):
+    """Removed in round 2."""
+    raise RuntimeError("cascade_amd.parallel.merge_events is gone: use merge_conjunctions(parts) / gather_conjunctions(sim)")
+
+
 def merge_conjunctions(parts):
     """parts: per process, (records, segments) as ``sim.conjunctions`` / ``sim._conj_segments``
     give them. Returns the list of the unsharded simulation: superstep by superstep, the records
