@@ -137,6 +137,7 @@ SYMBOLS = {
     "csc_narrow_phase": (_i32, [_vp, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _dbl, _u32] + [_vp] * 8 + [C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u32)]),
     "csc_propagate_range": (_i32, [_vp, C.POINTER(PropCfg), _u32, _u32, _u32] + [_vp] * 10),
     "csc_propagate_range_rows": (_i32, [_vp, C.POINTER(PropCfg), _u32, _u32, _u32] + [_vp] * 10 + [_u32]),
+    "csc_wave_plan_eval": (_i32, [_vp, _u32, _u32, _vp, _i32, _u32, _vp, _vp, C.c_double, _vp, _vp]),
     "csc_shard_record_bytes": (_sz, [_u32]),
     "csc_shard_pack": (_i32, [_vp, _u32, _u32, _u32, _u32] + [_vp] * 10),
     "csc_shard_unpack": (_i32, [_vp, _u32, _u32] + [_vp] * 10),

@@ -142,6 +142,7 @@ struct csc_ctx {
     // "wave_ops" / "wave_ops0". wave_mode: -1 read CASCADE_WAVE once; 0 off; 1 on.
     std::vector<csc_tape_op> wave_tape;
     csc::wave_plan wave_plan;
+    bool wave_fits = false;
     int wave_mode = -1;
     bool pass1_wave = false; // the last pass 1 ran k_propagate_wave: the store pass then does too (same substeps)
     float4 *na_scratch = nullptr;       // device address of `scratch` on this context's device
@@ -1330,56 +1331,38 @@ static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::pro
         const char *e = std::getenv("CASCADE_WAVE");
         ctx->wave_mode = (e && std::atoi(e) == 0) ? 0 : 1;
     }
-    // (the hand-unrolled kernels of the built-in dynamics are faster than this one: 16 against
-    // ~170 ns per object-substep for J2 + drag, whose generic tape has 83 operations for 17 hand-picked series)
+    // (the hand-unrolled kernels of the built-in dynamics are faster than this one)
     if (ctx->wave_mode != 1 || cfg->order != 20u || cfg->tape == nullptr || cfg->dyn_kind != CSC_DYN_TAPE) {
-        return CSC_OK;
-    }
-    const int wave_ng = csc::wave_pick_ng(cfg->tape_nslots, cfg->tape_nops, cfg->order);
-    if (wave_ng == 0) {
         return CSC_OK;
     }
     static_assert(sizeof(csc_tape_op) == sizeof(csc::tape_op), "tape layout");
     const size_t bytes = static_cast<size_t>(cfg->tape_nops) * sizeof(csc_tape_op);
     const bool fresh = ctx->wave_tape.size() != cfg->tape_nops || std::memcmp(ctx->wave_tape.data(), cfg->tape, bytes) != 0
-                       || ctx->wave_plan.ng != static_cast<uint32_t>(wave_ng) || ctx->wave_plan.nslots != cfg->tape_nslots
-                       || std::memcmp(ctx->wave_plan.rhs, cfg->tape_rhs, sizeof(cfg->tape_rhs)) != 0;
+                       || ctx->wave_plan.tape_nslots != cfg->tape_nslots
+                       || std::memcmp(ctx->wave_plan.tape_rhs, cfg->tape_rhs, sizeof(cfg->tape_rhs)) != 0;
     if (fresh) {
         ctx->wave_tape.assign(cfg->tape, cfg->tape + cfg->tape_nops);
-        csc::wave_build_plan(reinterpret_cast<const csc::tape_op *>(cfg->tape), cfg->tape_nops, cfg->tape_nslots, cfg->tape_rhs, wave_ng,
-                             cfg->order, ctx->wave_plan);
+        ctx->wave_fits = csc::wave_build_plan(reinterpret_cast<const csc::tape_op *>(cfg->tape), cfg->tape_nops, cfg->tape_nslots,
+                                              cfg->tape_rhs, 0, cfg->order, ctx->wave_plan);
     }
     const csc::wave_plan &wp = ctx->wave_plan;
-    if (fresh && std::getenv("CASCADE_WAVE_DEBUG")) {
-        std::fprintf(stderr, "[wave] tape: %u operations, %u slots -> %u groups per object, %u rows, %zu bytes of LDS per wave\n", cfg->tape_nops,
-                     cfg->tape_nslots, wp.ng, wp.nrows, wp.lds_bytes());
-    }
-    // Two waves per compute unit at least: beyond that (simple_earth with every term: 451 operations,
-    // 110 KB per object) the one-lane-per-object interpreter with its global workspace is faster.
-    if (wp.lds_bytes() > csc::WAVE_LDS_MAX / 2u && !std::getenv("CASCADE_WAVE_NG")) {
+    // Two waves per compute unit at least: with less, the one-lane-per-object interpreter with its
+    // global workspace is the faster one.
+    if (!ctx->wave_fits || (wp.waves_per_cu() < 2u && !std::getenv("CASCADE_WAVE_NG"))) {
+        if (fresh && std::getenv("CASCADE_WAVE_DEBUG")) {
+            std::fprintf(stderr, "[wave] not used: %s\n", ctx->wave_fits ? "fewer than two waves per compute unit" : "the tape has no schedule");
+        }
         return CSC_OK;
     }
-    if (wp.lds_bytes() > csc::WAVE_LDS_MAX) {
-        return CSC_OK;
-    }
-    CSC_BUF(d_wops, csc::wave_op, "wave_ops", wp.ops.size());
+    CSC_BUF(d_wblk, uint32_t, "wave_blk", wp.blk.size());
     CSC_BUF(d_wops0, csc::wave_op0, "wave_ops0", wp.ops0.size());
     if (fresh) {
-        CSC_HIP(hipMemcpyAsync(d_wops, wp.ops.data(), wp.ops.size() * sizeof(csc::wave_op), hipMemcpyHostToDevice, ctx->stream));
+        CSC_HIP(hipMemcpyAsync(d_wblk, wp.blk.data(), wp.blk_bytes(), hipMemcpyHostToDevice, ctx->stream));
         CSC_HIP(hipMemcpyAsync(d_wops0, wp.ops0.data(), wp.ops0.size() * sizeof(csc::wave_op0), hipMemcpyHostToDevice, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
     }
-    csc::wave_sched ws{};
-    ws.ops = d_wops;
-    ws.ops0 = d_wops0;
-    ws.nrows = wp.nrows;
-    ws.nslots = wp.nslots;
-    ws.obj_doubles = wp.obj_doubles;
-    for (int c = 0; c < 7; ++c) {
-        ws.rhs[c] = wp.rhs[c];
-    }
     hipError_t lrc = hipSuccess;
-    KT(p.nsub_in ? "k_propagate_wave_store" : "k_propagate_wave", lrc = csc::wave_launch(wave_ng, events, p, ws, wp.lds_bytes(), ctx->stream));
+    KT(p.nsub_in ? "k_propagate_wave_store" : "k_propagate_wave", lrc = csc::wave_launch(wp, d_wblk, d_wops0, events, p, ctx->stream));
     if (lrc != hipSuccess) {
         return ctx->fail(lrc, "k_propagate_wave launch");
     }

@@ -11,15 +11,20 @@
 // global workspace: 2 k dependent memory round trips per substep behind one wave per SIMD (16 ns
 // per object-substep for J2 + drag, 570 ns for the tape interpreter). Here an object owns 8 NG
 // lanes (NG = 1, 2, 4 or 8: 8 to 64 lanes) and ALL its series live in LDS, [slot][order]. The
-// tape is scheduled on the host into rows of up to NG mutually independent operations; per Taylor
-// order and row, each 8-lane group takes one operation: its lanes split the convolution sum
-// (terms j = jlo + lane, + 8, + 16), three DPP steps add the partial sums, lane 0 stores the
-// coefficient. Every automatic-differentiation recurrence (product, quotient, power, square
-// root, exponential, sine / cosine) has the form
-//     c[n] = (a1 L1[n] + a2 L2[n] + sg * sum_j (n wa + j wb + wc) A[j] B[n - j]) * pm * (1 / n)?
-// so the row code is data-driven (wave_op) and the groups of a wave never diverge. Order 0
-// (the transcendental functions themselves) is evaluated once per substep, one lane per
-// operation, and leaves the order-independent factor pm (1 / b0, 1 / (2 c0), a scalar ...) in LDS.
+// host (cascade_wave.hip) first FUSES the tape: sums, differences, scalings and products are
+// folded into sum-of-products operations (x^2 + y^2 + z^2 is one operation, a quotient takes a
+// whole expression as its numerator), which for the reference's default dynamics leaves 46 of 132
+// operations, 54 of 140 series and 8 of 17 dependency levels. The fused operations are scheduled
+// into rows of up to NG mutually independent ones; per Taylor order and row, each 8-lane group
+// takes one operation: its lanes split the convolution sums (terms j = jlo + lane, + 8, + 16) and
+// the linear terms, three DPP steps add the partial sums, and the coefficient is stored. Every
+// automatic-differentiation recurrence (sum of products, quotient, power, square root,
+// exponential, sine / cosine) has the form
+//     c[n] = (sum_m a_m L_m[n] + sum_k sum_j (n wa_k + j wb_k + wc_k) A_k[j] B_k[n - j]) * pm * (1 / n)?
+// so the row code is data-driven (wave_hdr / wave_lin / wave_conv) and the groups of a wave never
+// diverge. Order 0 runs through the same rows; there the sums give the arguments, a switch applies
+// the function itself and leaves the order-independent factor pm (1 / b0, 1 / (2 c0), a runtime
+// parameter ...) in LDS.
 //
 // The summation order differs from oracle/orc.hpp::tape_compute_tcs (8 partial sums, then a tree),
 // so the coefficients agree with the oracle to rounding (1e-15 relative), not bit for bit; the
@@ -37,32 +42,46 @@
 namespace csc
 {
 
-// Orders >= 1 of one scheduled operation, 32 bytes.
-struct wave_op {
-    std::uint32_t s;   // sa | sb << 16: operands of the sum, A indexed by j, B by n - j
-    std::uint32_t l;   // l1 | l2 << 16: linear terms (none: slot 0 with coefficient 0)
-    std::uint32_t d;   // dst | jlo << 16 | jhi_off << 20 (sum over j = jlo .. n - jhi_off)
-    std::uint32_t f;   // int8 a1 | int8 a2 << 8 | int8 sg << 16 | flags << 24
-    double wa, wb;     // weight of term j: n wa + j wb + wc (wc = flag)
+// The schedule, in 16-byte units [row][unit][group]: unit 0 the header, units 1..4 the linear
+// terms (taken by lanes 0..3 of the group), units 5 + 2 k, 6 + 2 k the k-th convolution sum.
+// Series are addressed by their byte offset within the object (slot x (P + 1) x 8).
+struct wave_hdr {
+    std::uint32_t dst, flags; // (dst: byte offset)
+    std::uint32_t nk; // convolution sums of the ROW (the most of any of its operations)
+    std::uint32_t pad;
 };
-enum : std::uint32_t { WF_VALID = 1, WF_TIME = 2, WF_WC = 4, WF_DIVN = 8, WF_SUM = 16 };
-static_assert(sizeof(wave_op) == 32, "wave_op layout");
+struct wave_lin {
+    std::uint32_t off, pad; // (no term: offset 0 with coefficient 0)
+    double coef;
+};
+// sum over j = jlo .. n - hoff of (n wa + j wb + wc) A[j] B[n - j], as terms jj = j - jlo = 0 .. n - (jlo + hoff):
+struct wave_conv {
+    std::uint32_t a; // byte offset of A[jlo] | (jlo + hoff) << 20 (no sum: 0xfff << 20)
+    std::int32_t b;  // byte offset of B[-jlo]: term jj reads B at b + 8 (n - jj)
+    double wa, wb, wc; // weight of term jj: n wa + jj wb + wc (wc includes jlo wb)
+};
+enum : std::uint32_t { WF_TIME = 1, WF_DIVN = 2 };
+constexpr std::uint32_t WAVE_LIN_MAX = 4, WAVE_CONV_MAX = 4, WAVE_LDS_PAD = 24;
+static_assert(sizeof(wave_hdr) == 16 && sizeof(wave_lin) == 16 && sizeof(wave_conv) == 32, "schedule layout");
 
-// Order 0 of one scheduled operation, 32 bytes: the tape operation and what it leaves in pm.
+// Order 0 of one scheduled operation, 32 bytes: what to do with the sums of order 0, and what to leave in pm.
 struct wave_op0 {
-    std::int32_t op, dst, a, b; // (op 0: nothing to do)
-    double c;
-    std::int32_t pm_kind, pm_slot;
+    std::int32_t kind;
+    std::int32_t a;   // operand whose order 0 the function takes (denominator, base, argument)
+    std::int32_t par; // runtime parameter (>= 0) in place of c / as the factor of a sum of products
+    std::int32_t pad; // (sum of products: 1 when the parameter divides)
+    double c;         // exponent of a power, numerator of scalar / series
+    double pad2;
 };
-enum : std::int32_t { PM_ONE = 0, PM_SCALAR, PM_INV_SCALAR, PM_INV_SLOT0, PM_INV_2DST0 };
-constexpr std::int32_t TP_WAVE_COS = 100;
+enum : std::int32_t { WK_FUSED = 0, WK_DIV, WK_SQRT, WK_POW, WK_EXP, WK_SIN, WK_COS, WK_RDIV, WK_TIME };
 static_assert(sizeof(wave_op0) == 32, "wave_op0 layout");
 
 struct wave_sched {
-    const wave_op *ops;   // [nrows][NG]
+    const uint4 *blk;     // [nrows][row_units][NG]
     const wave_op0 *ops0; // [nrows][NG]
-    std::uint32_t nrows, nslots;
-    std::uint32_t obj_doubles; // LDS doubles per object
+    std::uint32_t nrows, nslots; // nslots: the series of an object, the constant series `one` included, the spare one behind them not
+    std::uint32_t obj_doubles;   // LDS doubles per object
+    std::uint32_t row_units, one;
     std::int32_t rhs[7];
 };
 
@@ -116,33 +135,121 @@ CSC_DEV double wave_event_root(const double *gs, double h, int direction, int *f
     return event_first_root<P>(g, h, direction, flags);
 }
 
-template <int P, int NG, bool EVENTS>
-__global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, const wave_sched sc)
+CSC_DEV double u2d(std::uint32_t lo, std::uint32_t hi)
+{
+    return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+}
+
+// NK convolution sums of one operation at order n, the terms of each over the 8 lanes of the group in
+// TR trips (lane `sub` of LPG takes jj = sub, sub + LPG, ... of 0 .. n - (jlo + hoff)); cv: the NK
+// wave_conv units as loaded.
+struct wave_conv_ctx {
+    const char *Ws, *Wnb; // the object's series + 8 sub; + 8 n - 8 sub
+    int n, sub;
+    double dn, dsub;
+};
+template <int NK, int TR, int LPG>
+CSC_DEV double wave_conv_sums(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_conv_ctx &c, double acc)
+{
+    double av[NK][TR], bv[NK][TR];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        // (a lane beyond the range reads a neighbouring series or the padding in front of the first: not used)
+        const char *pa = c.Ws + (cv[2 * k].x & 0xfffffu), *pb = c.Wnb + static_cast<int>(cv[2 * k].y);
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            av[k][t] = *reinterpret_cast<const double *>(pa + 8 * LPG * t);
+            bv[k][t] = *reinterpret_cast<const double *>(pb - 8 * LPG * t);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int lim = c.n - static_cast<int>(cv[2 * k].x >> 20) - c.sub;
+        const double wb = u2d(cv[2 * k + 1].x, cv[2 * k + 1].y);
+        double w = fma(c.dsub, wb, fma(c.dn, u2d(cv[2 * k].z, cv[2 * k].w), u2d(cv[2 * k + 1].z, cv[2 * k + 1].w)));
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const double p = fma(w * av[k][t], bv[k][t], acc);
+            acc = lim >= LPG * t ? p : acc;
+            w = fma(static_cast<double>(LPG), wb, w);
+        }
+    }
+    return acc;
+}
+
+template <int NK, int LPG>
+CSC_DEV double wave_conv_trips(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_conv_ctx &c, double acc, int trips)
+{
+    switch (trips) {
+        case 1:
+            return wave_conv_sums<NK, 1, LPG>(cv, c, acc);
+        case 2:
+            return wave_conv_sums<NK, 2, LPG>(cv, c, acc);
+        case 3:
+            return wave_conv_sums<NK, 3, LPG>(cv, c, acc);
+        case 4:
+            if constexpr (LPG < 8) {
+                return wave_conv_sums<NK, 4, LPG>(cv, c, acc);
+            }
+            return acc;
+        default:
+            if constexpr (LPG < 8) {
+                return wave_conv_sums<NK, 5, LPG>(cv, c, acc);
+            }
+            return acc;
+    }
+}
+
+// Sum over the LPG lanes of a group (every lane gets the result).
+template <int LPG>
+CSC_DEV double group_sum(double v)
+{
+    v += dpp_f64<0xB1>(v); // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E>(v); // quad_perm [2, 3, 0, 1]
+    if constexpr (LPG == 8) {
+        v += dpp_f64<0x141>(v); // row_half_mirror: lane i <-> 7 - i of each 8
+    }
+    return v;
+}
+
+// A workgroup is 1 to 4 waves that share nothing but the copy of the schedule in LDS: after the
+// copy every wave works through its own objects and synchronises with itself only.
+template <int P, int NG, int LPG, bool EVENTS>
+__global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm, const wave_sched sc)
 {
     extern __shared__ double lds[];
     constexpr int L = P + 1;
-    constexpr int LPO = 8 * NG;    // lanes per object
+    static_assert((LPG == 4 || LPG == 8) && LPG * NG >= 8 && LPG * NG <= 64, "lanes per object");
+    constexpr int LPO = LPG * NG;  // lanes per object
     constexpr int OPW = 64 / LPO;  // objects per wave
-    const int lane = threadIdx.x;
-    const int sub = lane & 7, grp = (lane >> 3) % NG, ow = lane / LPO, lo = lane % LPO;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    // sub / grp: the lane's place in the rows (LPG lanes per operation); sub8: its place among 8
+    // aligned lanes, for the parts that give a lane to each state variable.
+    const int sub = lane % LPG, grp = (lane / LPG) % NG, sub8 = lane & 7, ow = lane / LPO, lo = lane % LPO;
     const unsigned long long omask = (LPO == 64 ? ~0ull : ((1ull << LPO) - 1ull)) << (ow * LPO);
-    double *W = lds + static_cast<std::size_t>(ow) * sc.obj_doubles;
+    // (WAVE_LDS_PAD doubles in front: a lane beyond the range of a sum may read up to 23 doubles before its series)
+    double *W = lds + WAVE_LDS_PAD + static_cast<std::size_t>(wv * OPW + ow) * sc.obj_doubles;
+    char *Wb = reinterpret_cast<char *>(W);
+    const char *Ws = Wb + 8 * sub;
+    const double dsub = static_cast<double>(sub);
     double *pm = W + static_cast<std::size_t>(sc.nslots + 1u) * L; // [nrows][NG] (behind the series and one spare slot)
     double *gs = pm + static_cast<std::size_t>(sc.nrows) * NG; // [L] event polynomial / broadcast scratch
-    // The schedule of the orders >= 1 is read nrows x (P - 1) times per substep: a copy in LDS,
-    // behind the objects' series (2 x 16 bytes per row and group, the same address for 8 lanes).
-    uint4 *lops = reinterpret_cast<uint4 *>(lds + static_cast<std::size_t>(OPW) * sc.obj_doubles);
-    for (std::uint32_t k = lane; k < sc.nrows * NG * 2u; k += 64u) {
-        lops[k] = reinterpret_cast<const uint4 *>(sc.ops)[k];
+    // The schedule is read nrows x P times per substep: a copy in LDS behind the objects' series
+    // (the 8 lanes of a group read the same 16 bytes).
+    uint4 *lops = reinterpret_cast<uint4 *>(lds + WAVE_LDS_PAD + static_cast<std::size_t>(wpb * OPW) * sc.obj_doubles);
+    const std::uint32_t RUN = sc.row_units * NG; // 16-byte units per row
+    for (std::uint32_t k = threadIdx.x; k < sc.nrows * RUN; k += blockDim.x) {
+        lops[k] = sc.blk[k];
     }
-    wave_lds_sync();
-    const uint4 *ops = lops + 2 * grp;
+    __syncthreads();
+    const uint4 *rowp = lops + grp;
+    const int lin_unit = (1 + (sub & 3)) * NG;
     const wave_op0 *ops0 = sc.ops0 + grp;
     const dfl init_time{prm.init_hi, prm.init_lo};
     const dfl t_end = df_add(init_time, df(prm.delta_t));
     constexpr int XS = tc_xyz_stride(P), VS = tc_vr_stride(P);
 
-    for (std::uint32_t base = blockIdx.x * OPW; base < prm.n; base += gridDim.x * OPW) {
+    for (std::uint32_t base = (blockIdx.x * wpb + wv) * OPW; base < prm.n; base += gridDim.x * wpb * OPW) {
         const std::uint32_t k_obj = base + ow;
         const bool exists = k_obj < prm.n;
         const std::uint32_t kk = exists ? k_obj : prm.n - 1u;
@@ -153,6 +260,9 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
         const double *pars = prm.pars + static_cast<std::size_t>(i) * prm.npars;
         if (lo < 6) {
             W[lo * L] = sp[lo];
+        }
+        for (int e = lo; e < L; e += LPO) {
+            W[sc.one * L + e] = e == 0 ? 1. : 0.; // the constant series (additive constants are its multiples)
         }
         wave_lds_sync();
         if (lo == 6) {
@@ -174,132 +284,111 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
             const dfl rem = df_sub(t_end, tm);
             const double max_dt = rem.hi > 0. ? rem.hi : 0.;
 
-            // ---- order 0 of every operation, and its order-independent factor ----
-            for (std::uint32_t r = 0; r < sc.nrows; ++r) {
-                const wave_op0 o = ops0[static_cast<std::size_t>(r) * NG];
-                if (o.op != 0) {
-                    double sv = o.c;
-                    if (o.b <= -2) {
-                        sv = pars[-2 - o.b];
-                    }
-                    const double a0 = W[o.a * L];
-                    const double b0 = o.b >= 0 ? W[o.b * L] : sv;
-                    double res;
-                    switch (o.op) {
-                        case TP_ADD:
-                            res = a0 + b0;
-                            break;
-                        case TP_SUB:
-                            res = a0 - b0;
-                            break;
-                        case TP_RSUB:
-                            res = sv - a0;
-                            break;
-                        case TP_MUL:
-                            res = a0 * b0;
-                            break;
-                        case TP_DIV:
-                            res = a0 / b0;
-                            break;
-                        case TP_RDIV:
-                            res = sv / a0;
-                            break;
-                        case TP_SQR:
-                            res = a0 * a0;
-                            break;
-                        case TP_POW:
-                            res = pow_order0(a0, o.c);
-                            break;
-                        case TP_SQRT:
-                            res = sqrt(a0);
-                            break;
-                        case TP_EXP:
-                            res = det_exp(a0);
-                            break;
-                        case TP_SINCOS:
-                            res = sin(a0);
-                            break;
-                        case TP_WAVE_COS: // (the cosine half of a TP_SINCOS: an operation of its own here)
-                            res = cos(a0);
-                            break;
-                        case TP_TIME:
-                            res = tm.hi;
-                            break;
-                        default: // TP_CONST
-                            res = sv;
-                            break;
-                    }
-                    double pv = 1.;
-                    switch (o.pm_kind) {
-                        case PM_SCALAR:
-                            pv = sv;
-                            break;
-                        case PM_INV_SCALAR:
-                            pv = 1. / sv;
-                            break;
-                        case PM_INV_SLOT0:
-                            pv = 1. / W[o.pm_slot * L];
-                            break;
-                        case PM_INV_2DST0:
-                            pv = 1. / (2. * res);
-                            break;
-                        default:
-                            break;
-                    }
-                    if (sub == 0) {
-                        W[o.dst * L] = res;
-                        pm[r * NG + grp] = pv;
-                    }
+            // ---- orders 0 .. P - 1 of every operation; order n of the right-hand side gives order n + 1 of the state ----
+            for (int n = 0; n < P; ++n) {
+                const double dn = static_cast<double>(n), rn = n > 0 ? 1. / dn : 1.;
+                const int trips = (n + LPG) / LPG;
+                const char *Wn = Wb + 8 * n;      // + offset of a series: its order n
+                const char *Wnb = Wn - 8 * sub;   // ... its order n - sub
+                uint4 nh = rowp[0], nl = rowp[lin_unit];
+                uint4 ncv[2 * WAVE_CONV_MAX];
+#pragma unroll
+                for (int u = 0; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
+                    ncv[u] = rowp[(5 + u) * NG];
                 }
-                wave_lds_sync();
-            }
-            if (lo < 7) {
-                W[lo * L + 1] = W[sc.rhs[lo] * L];
-            }
-            wave_lds_sync();
-
-            // ---- orders 1 .. P - 1 ----
-            for (int n = 1; n < P; ++n) {
-                const double dn = static_cast<double>(n), rn = 1. / dn;
-                const int trips = (n + 8) >> 3;
-                uint4 nx0 = ops[0], nx1 = ops[1];
                 for (std::uint32_t r = 0; r < sc.nrows; ++r) {
-                    // (the next row's descriptor is requested before this row's work starts)
-                    const uint4 o0 = nx0, o1 = nx1;
-                    const std::uint32_t rn1 = r + 1u < sc.nrows ? r + 1u : 0u;
-                    nx0 = ops[rn1 * (2 * NG)];
-                    nx1 = ops[rn1 * (2 * NG) + 1];
-                    const std::uint32_t of = o0.w, fl = of >> 24;
-                    const int sa = o0.x & 0xffffu, sb = o0.x >> 16;
-                    const int l1 = o0.y & 0xffffu, l2 = o0.y >> 16;
-                    const int dst = o0.z & 0xffffu, jlo = (o0.z >> 16) & 0xf, jhi = n - static_cast<int>((o0.z >> 20) & 0xf);
-                    const double a1 = static_cast<double>(static_cast<std::int8_t>(of & 0xffu));
-                    const double a2 = static_cast<double>(static_cast<std::int8_t>((of >> 8) & 0xffu));
-                    const double sg = static_cast<double>(static_cast<std::int8_t>((of >> 16) & 0xffu));
-                    const double owa = __hiloint2double(static_cast<int>(o1.y), static_cast<int>(o1.x));
-                    const double owb = __hiloint2double(static_cast<int>(o1.w), static_cast<int>(o1.z));
-                    // No branches below except the wave-uniform one around the sum: a row without a
-                    // linear term reads slot 0 with coefficient 0, an empty place in a row writes
-                    // to the spare slot behind the series, all 8 lanes store the (same) result.
-                    const double l1v = W[l1 * L + n], l2v = W[l2 * L + n], pmv = pm[r * NG + grp];
-                    double acc = 0.;
-                    if (__any((fl & WF_SUM) != 0u)) {
-                        const double wn = fma(dn, owa, (fl & WF_WC) ? 1. : 0.);
-                        const double *pa = W + sa * L, *pb = W + sb * L + n;
-                        for (int t = 0; t < trips; ++t) {
-                            const int j = jlo + sub + 8 * t;
-                            const bool ok = (fl & WF_SUM) != 0u && j <= jhi;
-                            const int jj = ok ? j : jlo;
-                            const double av = pa[jj], bv = pb[-jj];
-                            const double w = fma(static_cast<double>(jj), owb, wn);
-                            acc = ok ? fma(w * av, bv, acc) : acc;
-                        }
-                        acc = group8_sum(acc);
+                    // (the next row's header, linear term and sums are requested before this row's work starts)
+                    const uint4 hd = nh, ln = nl;
+                    uint4 cv[2 * WAVE_CONV_MAX];
+                    const uint4 *np = rowp + (r + 1u < sc.nrows ? r + 1u : 0u) * RUN;
+#pragma unroll
+                    for (int u = 0; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
+                        cv[u] = ncv[u];
                     }
-                    double res = fma(sg, acc, fma(a2, l2v, a1 * l1v)) * pmv;
-                    res = (fl & WF_DIVN) ? res * rn : res;
-                    res = (fl & WF_TIME) ? (n == 1 ? 1. : 0.) : res;
-                    W[dst * L + n] = res;
+                    nh = np[0];
+                    nl = np[lin_unit];
+#pragma unroll
+                    for (int u = 0; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
+                        ncv[u] = np[(5 + u) * NG];
+                    }
+                    const std::uint32_t fl = hd.y;
+                    const int nk = __builtin_amdgcn_readfirstlane(static_cast<int>(hd.z));
+                    // No branches below except wave-uniform ones: an absent linear term reads offset 0
+                    // with coefficient 0, an absent sum has an empty range, an empty place in a row
+                    // writes to the spare slot behind the series, all 8 lanes store the (same) result.
+                    const double pmv = pm[r * NG + grp]; // (order 0 writes it below and does not use it)
+                    double acc = u2d(ln.z, ln.w) * *reinterpret_cast<const double *>(Wn + ln.x);
+                    if constexpr (LPG == 8) {
+                        acc = sub < 4 ? acc : 0.;
+                    }
+                    // The sums of the row, straight-line code per (sums, trips): every operand is
+                    // requested before the first product, so a row costs one LDS round trip, not one per sum.
+                    const wave_conv_ctx cc{Ws, Wnb, n, sub, dn, dsub};
+                    switch (nk) {
+                        case 1:
+                            acc = wave_conv_trips<1, LPG>(cv, cc, acc, trips);
+                            break;
+                        case 2:
+                            acc = wave_conv_trips<2, LPG>(cv, cc, acc, trips);
+                            break;
+                        case 3:
+                            acc = wave_conv_trips<3, LPG>(cv, cc, acc, trips);
+                            break;
+                        case 4:
+                            acc = wave_conv_trips<4, LPG>(cv, cc, acc, trips);
+                            break;
+                        default: // (a row without sums)
+                            break;
+                    }
+                    acc = group_sum<LPG>(acc);
+                    if (n == 0) {
+                        // The functions themselves, and the order-independent factor of the recurrence.
+                        const wave_op0 o = ops0[static_cast<std::size_t>(r) * NG];
+                        const double sv = o.par >= 0 ? pars[o.par] : o.c;
+                        const double a0 = W[o.a * L];
+                        double res = acc, pv = 1.;
+                        switch (o.kind) {
+                            case WK_DIV:
+                                res = acc / a0;
+                                pv = 1. / a0;
+                                break;
+                            case WK_SQRT:
+                                res = sqrt(acc);
+                                pv = 1. / (2. * res);
+                                break;
+                            case WK_POW:
+                                res = pow_order0(a0, o.c);
+                                pv = 1. / a0;
+                                break;
+                            case WK_EXP:
+                                res = det_exp(a0);
+                                break;
+                            case WK_SIN:
+                                res = sin(a0);
+                                break;
+                            case WK_COS:
+                                res = cos(a0);
+                                break;
+                            case WK_RDIV:
+                                res = sv / a0;
+                                pv = 1. / a0;
+                                break;
+                            case WK_TIME:
+                                res = tm.hi;
+                                break;
+                            default: // WK_FUSED: a sum of products, times a runtime parameter if it has one
+                                pv = o.par >= 0 ? (o.pad != 0 ? 1. / sv : sv) : 1.;
+                                res = acc * pv;
+                                break;
+                        }
+                        pm[r * NG + grp] = pv;
+                        *reinterpret_cast<double *>(Wb + hd.x) = res;
+                    } else {
+                        double res = acc * pmv;
+                        res = (fl & WF_DIVN) ? res * rn : res;
+                        res = (fl & WF_TIME) ? (n == 1 ? 1. : 0.) : res;
+                        *reinterpret_cast<double *>(Wb + hd.x + 8 * n) = res;
+                    }
                     wave_lds_sync();
                 }
                 if (lo < 7) {
@@ -311,9 +400,9 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
             // ---- step size (Jorba-Zou; heyoka, EXTERNAL) ----
             double m0 = 0., mo = 0., mom1 = 0.;
             bool badl = false;
-            if (sub < 7) {
-                // (every group of the object does it: no broadcast needed)
-                const double a0 = fabs(W[sub * L]), ao = fabs(W[sub * L + P]), aom1 = fabs(W[sub * L + P - 1]);
+            if (sub8 < 7) {
+                // (every 8 lanes of the object do it: no broadcast needed)
+                const double a0 = fabs(W[sub8 * L]), ao = fabs(W[sub8 * L + P]), aom1 = fabs(W[sub8 * L + P - 1]);
                 badl = !finite_d(a0) || !finite_d(ao) || !finite_d(aom1);
                 m0 = a0;
                 mo = ao;
@@ -347,6 +436,21 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
             if constexpr (EVENTS) {
                 double ev_t = 0.;
                 std::uint32_t idx = 0;
+                // Where the object can be during the step, from the series of r (the 7th state
+                // variable): r0 -+ sum |r_n| h^n. Nearly every step stays clear of both surfaces by
+                // hundreds of kilometres; the event polynomial and its root search are for the others.
+                double rlo, rhi;
+                {
+                    const double *c = W + 6 * L;
+                    double sabs = fabs(c[P]);
+#pragma unroll
+                    for (int o = P - 1; o >= 1; --o) {
+                        sabs = fma(sabs, h, fabs(c[o]));
+                    }
+                    const double dev = sabs * h;
+                    rlo = c[0] - dev;
+                    rhi = c[0] + dev;
+                }
                 for (int e = 0; e < 2; ++e) {
                     const bool on = e == 0 ? prm.has_exit != 0 : prm.has_reentry != 0;
                     if (!on) {
@@ -354,6 +458,21 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
                     }
                     const double kx = e == 0 ? 1. : prm.re_k[0], ky = e == 0 ? 1. : prm.re_k[1], kz = e == 0 ? 1. : prm.re_k[2];
                     const double c0 = e == 0 ? prm.exit_c0 : prm.re_c0;
+                    // g(t) = kx x^2 + ky y^2 + kz z^2 - c0 >= kmin |p|^2 - c0 (reentry), = |p|^2 - c0 (exit):
+                    // no root while the bound keeps its sign, with a margin of 1e-9 for what separates
+                    // the series of r from the norm of the truncated position polynomials (1e-16).
+                    // (written so that a NaN anywhere keeps the search)
+                    bool may = alive && !stop_nf && h > 0.;
+                    if (e == 0) {
+                        may = may && !(rhi * rhi < c0 * (1. - 1e-9));
+                    } else {
+                        const double kmin = dmin(kx, dmin(ky, kz));
+                        may = may && !(rlo > 0. && kmin > 0. && kmin * (rlo * rlo) > c0 * (1. + 1e-9));
+                    }
+                    if (!__any(may)) {
+                        idx = 1;
+                        continue;
+                    }
                     wave_lds_sync();
                     for (int n = lo; n <= P; n += LPO) {
                         double ax = 0., ay = 0., az = 0.;
@@ -365,7 +484,7 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
                         gs[n] = (kx * ax + ky * ay) + kz * az - (n == 0 ? c0 : 0.);
                     }
                     wave_lds_sync();
-                    if (alive && !stop_nf && h > 0.) {
+                    if (may) {
                         const double rt = wave_event_root<P>(gs, h, e == 0 ? 1 : -1, &flags);
                         if (rt >= 0. && (!ev_found || rt < ev_t)) {
                             ev_found = true;
@@ -384,8 +503,8 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
             // ---- advance: Horner of the 7 variables, double-length time ----
             double nv = 0.;
             bool finl = true;
-            if (sub < 7) {
-                const double *c = W + sub * L;
+            if (sub8 < 7) {
+                const double *c = W + sub8 * L;
                 double acc = c[P];
 #pragma unroll
                 for (int o = 1; o <= P; ++o) {
@@ -436,8 +555,8 @@ __global__ __launch_bounds__(64) void k_propagate_wave(const prop_params prm, co
                 ++ns;
             }
             wave_lds_sync();
-            if (step_ok && grp == 0 && sub < 7) {
-                W[sub * L] = nv;
+            if (step_ok && lo < 7) {
+                W[lo * L] = nv;
             }
             wave_lds_sync();
             if (step_ok) {

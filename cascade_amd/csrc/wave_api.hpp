@@ -1,8 +1,8 @@
 // cascade_amd/csrc/wave_api.hpp
 //
 // Host interface of the several-lanes-per-object propagation kernel (k_propagate_wave.hpp; its
-// translation unit is cascade_wave.hip): the tape scheduled into rows of mutually independent
-// operations, and the launch.
+// translation unit is cascade_wave.hip): the tape fused into sum-of-products operations and
+// scheduled into rows of mutually independent ones, and the launch.
 #pragma once
 
 #include <cstdint>
@@ -15,27 +15,46 @@
 namespace csc
 {
 
+constexpr std::size_t WAVE_LDS_MAX = 160u * 1024u;
+
 struct wave_plan {
-    std::vector<wave_op> ops;   // [nrows][ng]
-    std::vector<wave_op0> ops0; // [nrows][ng]
-    std::uint32_t nrows = 0, ng = 0, nslots = 0, obj_doubles = 0;
-    std::int32_t rhs[7] = {};
+    std::vector<std::uint32_t> blk; // [nrows][row_units][ng] 16-byte units, 4 words each
+    std::vector<wave_op0> ops0;     // [nrows][ng]
+    std::uint32_t nrows = 0, ng = 0, nslots = 0, obj_doubles = 0, row_units = 0, one = 0;
+    std::uint32_t lpg = 8;          // lanes that share one operation of a row (4 or 8): an object owns lpg x ng lanes
+    std::uint32_t wpb = 1;          // waves of a workgroup (they share the schedule in LDS)
+    // What it was built from, and what the fusion made of it.
+    std::uint32_t tape_nslots = 0, fused_ops = 0, depth = 0;
+    std::int32_t rhs[7] = {}, tape_rhs[7] = {};
+    [[nodiscard]] std::size_t blk_bytes() const
+    {
+        return blk.size() * sizeof(std::uint32_t);
+    }
+    [[nodiscard]] std::size_t wave_bytes() const
+    {
+        return static_cast<std::size_t>(64u / (lpg * ng)) * obj_doubles * sizeof(double);
+    }
+    // (of a workgroup: the objects' series of every wave, then the schedule)
     [[nodiscard]] std::size_t lds_bytes() const
     {
-        // (the objects' series, then the schedule of the orders >= 1)
-        return static_cast<std::size_t>(64u / (8u * ng)) * obj_doubles * sizeof(double) + static_cast<std::size_t>(nrows) * ng * 32u;
+        return WAVE_LDS_PAD * sizeof(double) + wpb * wave_bytes() + blk_bytes();
+    }
+    [[nodiscard]] unsigned waves_per_cu() const
+    {
+        return static_cast<unsigned>(WAVE_LDS_MAX / lds_bytes()) * wpb;
     }
 };
 
-constexpr std::size_t WAVE_LDS_MAX = 160u * 1024u;
-
-// Groups per object (1, 2, 4, 8) for a tape with `nslots` series at order P (0: the series of one
-// object do not fit the LDS of a compute unit).
-int wave_pick_ng(std::uint32_t nslots, std::uint32_t nops, std::uint32_t order);
-// Schedules the tape (validated by check_cfg) for `ng` groups per object.
-void wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslots, const std::int32_t rhs[7], int ng,
+// Fuses and schedules the tape (validated by check_cfg) for `ng` groups per object (1, 2, 4, 8; 0:
+// the layout with the best estimated throughput). False: the series of one object do not fit
+// the LDS of a compute unit.
+bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslots, const std::int32_t rhs[7], int ng,
                      std::uint32_t order, wave_plan &out);
-// Launches k_propagate_wave<20, ng, events> over prm.n objects (sc.ops / sc.ops0 on the device).
-hipError_t wave_launch(int ng, bool events, const prop_params &prm, const wave_sched &sc, std::size_t lds_bytes, hipStream_t stream);
+// Launches k_propagate_wave<20, plan.ng, plan.lpg, events> over prm.n objects (the plan's blk / ops0 on the device).
+hipError_t wave_launch(const wave_plan &plan, const std::uint32_t *d_blk, const wave_op0 *d_ops0, bool events, const prop_params &prm,
+                       hipStream_t stream);
+// The plan executed on the host, operation by operation as the kernel does (tests of the fusion
+// and the schedule without a GPU): Taylor coefficients [7][order + 1] of x, y, z, vx, vy, vz, r.
+void wave_plan_eval(const wave_plan &plan, std::uint32_t order, const double state[7], const double *pars, double time, double *out);
 
 } // namespace csc

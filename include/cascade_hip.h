@@ -443,6 +443,21 @@ int csc_propagate_range(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint3
 int csc_propagate_range_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, uint32_t first, uint32_t count,
                              const double *d_state, uint32_t *d_nsub, int32_t *d_status, uint32_t *d_ev_idx, double *d_ev_time,
                              double *d_nf_last_t, double *d_final_state, float *d_lbs, float *d_ubs, float *d_recs, uint32_t row_cap);
+/* Diagnostic, no GPU work and no context: the several-lanes-per-object kernel does not run the
+ * tape as given but a FUSED one (sums, differences, scalings and products folded into
+ * sum-of-products operations, scheduled into rows of independent operations for `ng` = 1, 2, 4, 8
+ * groups of 8 lanes per object; 0: the layout the library would pick). This builds that schedule
+ * and executes it on the host for one state (x, y, z, vx, vy, vz, r), operation by operation as
+ * the kernel does: out_coeffs[7][order + 1] are the Taylor coefficients of the state variables,
+ * to be compared with the plain tape's (heyoka's taylor_step in the reference,
+ * src/sim_basic.cpp:553-577 EXTERNAL; oracle/orc.hpp::tape_compute_tcs). out_stats (8 values, may
+ * be null): fused operations, series, dependency depth, rows, groups, LDS bytes per workgroup,
+ * waves per workgroup, lanes per operation. Returns 0, 1 (invalid arguments), 2 (the tape is
+ * not in single-assignment form or does not fit: the kernel is not used for it) or 3 (pars is
+ * null and the schedule reads a runtime parameter somewhere, an unused place of a row included). */
+int csc_wave_plan_eval(const void *tape /* csc_tape_op[nops] */, uint32_t nops, uint32_t nslots, const int32_t *rhs7, int ng,
+                       uint32_t order, const double *state7, const double *pars, double time, double *out_coeffs,
+                       uint32_t *out_stats);
 size_t csc_shard_record_bytes(uint32_t nchunks);
 int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t nchunks, const uint32_t *d_nsub,
                    const int32_t *d_status, const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,
