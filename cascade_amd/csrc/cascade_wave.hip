@@ -665,7 +665,8 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
         p.one = one;
         p.depth = depth;
         p.row_units = 1u + WAVE_LIN_MAX + 2u * kp;
-        p.obj_doubles = ((nslots_new + 1u) * L + p.nrows * p.ng + L + 1u) & ~1u;
+        // (zeros in front, the series and a spare one, one factor per place of a row, the event polynomial)
+        p.obj_doubles = (WAVE_OBJ_PAD + (nslots_new + 1u) * L + p.nrows * p.ng + L + 2u) & ~1u;
         p.blk.assign(static_cast<std::size_t>(p.nrows) * p.row_units * p.ng * 4u, 0u);
         p.ops0.assign(static_cast<std::size_t>(p.nrows) * p.ng, wave_op0{});
         for (std::uint32_t r = 0; r < p.nrows; ++r) {

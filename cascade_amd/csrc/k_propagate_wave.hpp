@@ -61,7 +61,10 @@ struct wave_conv {
     double wa, wb, wc; // weight of term jj: n wa + jj wb + wc (wc includes jlo wb)
 };
 enum : std::uint32_t { WF_TIME = 1, WF_DIVN = 2 };
-constexpr std::uint32_t WAVE_LIN_MAX = 4, WAVE_CONV_MAX = 4, WAVE_LDS_PAD = 24;
+// WAVE_OBJ_PAD doubles of zeros in front of every object's series (a term beyond the range of a
+// sum reads up to 21 doubles before a series); P_SERIES: coefficients of a series at order 20.
+constexpr std::uint32_t WAVE_LIN_MAX = 4, WAVE_CONV_MAX = 4, WAVE_OBJ_PAD = 24;
+constexpr int P_SERIES = 21;
 static_assert(sizeof(wave_hdr) == 16 && sizeof(wave_lin) == 16 && sizeof(wave_conv) == 32, "schedule layout");
 
 // Order 0 of one scheduled operation, 32 bytes: what to do with the sums of order 0, and what to leave in pm.
@@ -148,13 +151,17 @@ struct wave_conv_ctx {
     int n, sub;
     double dn, dsub;
 };
+// No lane is switched off: every coefficient of an order that has not been computed yet IS zero
+// (the series are cleared at the start of a substep), so the terms beyond the range of a sum read
+// a zero on the A side; what they read on the B side (lower slots of the same object, or the
+// zeros in front of its first series) is finite. With 8 lanes the third trip can leave the
+// series (terms 16 .. 23 of 21 coefficients): those lanes are masked.
 template <int NK, int TR, int LPG>
 CSC_DEV double wave_conv_sums(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_conv_ctx &c, double acc)
 {
     double av[NK][TR], bv[NK][TR];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        // (a lane beyond the range reads a neighbouring series or the padding in front of the first: not used)
         const char *pa = c.Ws + (cv[2 * k].x & 0xfffffu), *pb = c.Wnb + static_cast<int>(cv[2 * k].y);
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
@@ -164,13 +171,17 @@ CSC_DEV double wave_conv_sums(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_c
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int lim = c.n - static_cast<int>(cv[2 * k].x >> 20) - c.sub;
         const double wb = u2d(cv[2 * k + 1].x, cv[2 * k + 1].y);
         double w = fma(c.dsub, wb, fma(c.dn, u2d(cv[2 * k].z, cv[2 * k].w), u2d(cv[2 * k + 1].z, cv[2 * k + 1].w)));
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            const double p = fma(w * av[k][t], bv[k][t], acc);
-            acc = lim >= LPG * t ? p : acc;
+            if (LPG * (t + 1) > P_SERIES) {
+                const int lim = c.n - static_cast<int>(cv[2 * k].x >> 20) - c.sub;
+                const double p = fma(w * av[k][t], bv[k][t], acc);
+                acc = lim >= LPG * t ? p : acc;
+            } else {
+                acc = fma(w * av[k][t], bv[k][t], acc);
+            }
             w = fma(static_cast<double>(LPG), wb, w);
         }
     }
@@ -187,6 +198,7 @@ CSC_DEV double wave_conv_trips(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_
             return wave_conv_sums<NK, 2, LPG>(cv, c, acc);
         case 3:
             return wave_conv_sums<NK, 3, LPG>(cv, c, acc);
+        // (in two parts it was slower: 14.5 against 13.4 ms for the default dynamics)
         case 4:
             if constexpr (LPG < 8) {
                 return wave_conv_sums<NK, 4, LPG>(cv, c, acc);
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
     // aligned lanes, for the parts that give a lane to each state variable.
     const int sub = lane % LPG, grp = (lane / LPG) % NG, sub8 = lane & 7, ow = lane / LPO, lo = lane % LPO;
     const unsigned long long omask = (LPO == 64 ? ~0ull : ((1ull << LPO) - 1ull)) << (ow * LPO);
-    // (WAVE_LDS_PAD doubles in front: a lane beyond the range of a sum may read up to 23 doubles before its series)
-    double *W = lds + WAVE_LDS_PAD + static_cast<std::size_t>(wv * OPW + ow) * sc.obj_doubles;
+    static_assert(P + 1 == P_SERIES, "series length");
+    double *W = lds + WAVE_OBJ_PAD + static_cast<std::size_t>(wv * OPW + ow) * sc.obj_doubles;
     char *Wb = reinterpret_cast<char *>(W);
     const char *Ws = Wb + 8 * sub;
     const double dsub = static_cast<double>(sub);
@@ -236,12 +248,23 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
     double *gs = pm + static_cast<std::size_t>(sc.nrows) * NG; // [L] event polynomial / broadcast scratch
     // The schedule is read nrows x P times per substep: a copy in LDS behind the objects' series
     // (the 8 lanes of a group read the same 16 bytes).
-    uint4 *lops = reinterpret_cast<uint4 *>(lds + WAVE_LDS_PAD + static_cast<std::size_t>(wpb * OPW) * sc.obj_doubles);
+    uint4 *lops = reinterpret_cast<uint4 *>(lds + static_cast<std::size_t>(wpb * OPW) * sc.obj_doubles);
     const std::uint32_t RUN = sc.row_units * NG; // 16-byte units per row
     for (std::uint32_t k = threadIdx.x; k < sc.nrows * RUN; k += blockDim.x) {
         lops[k] = sc.blk[k];
     }
+    for (int e = lo; e < static_cast<int>(WAVE_OBJ_PAD); e += LPO) {
+        W[e - static_cast<int>(WAVE_OBJ_PAD)] = 0.;
+    }
     __syncthreads();
+    // Clears the series of the object (the spare one included; 16 bytes per lane and store).
+    const int clear_units = static_cast<int>(((sc.nslots + 1u) * L + 1u) / 2u);
+    const auto clear_series = [&]() {
+        double2 *z = reinterpret_cast<double2 *>(W);
+        for (int e = lo; e < clear_units; e += LPO) {
+            z[e] = double2{0., 0.};
+        }
+    };
     const uint4 *rowp = lops + grp;
     const int lin_unit = (1 + (sub & 3)) * NG;
     const wave_op0 *ops0 = sc.ops0 + grp;
@@ -258,11 +281,13 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
         const std::uint32_t i = store ? (prm.order != nullptr ? prm.order[kk] : kk) : prm.first + kk;
         const double *sp = prm.state + static_cast<std::size_t>(i) * 7u;
         const double *pars = prm.pars + static_cast<std::size_t>(i) * prm.npars;
+        clear_series();
+        wave_lds_sync();
         if (lo < 6) {
             W[lo * L] = sp[lo];
         }
-        for (int e = lo; e < L; e += LPO) {
-            W[sc.one * L + e] = e == 0 ? 1. : 0.; // the constant series (additive constants are its multiples)
+        if (lo == 7) {
+            W[sc.one * L] = 1.; // the constant series (additive constants are its multiples)
         }
         wave_lds_sync();
         if (lo == 6) {
@@ -291,26 +316,24 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
                 const char *Wn = Wb + 8 * n;      // + offset of a series: its order n
                 const char *Wnb = Wn - 8 * sub;   // ... its order n - sub
                 uint4 nh = rowp[0], nl = rowp[lin_unit];
-                uint4 ncv[2 * WAVE_CONV_MAX];
-#pragma unroll
-                for (int u = 0; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
-                    ncv[u] = rowp[(5 + u) * NG];
-                }
+                uint4 ncv[2] = {rowp[5 * NG], rowp[6 * NG]};
                 for (std::uint32_t r = 0; r < sc.nrows; ++r) {
                     // (the next row's header, linear term and sums are requested before this row's work starts)
                     const uint4 hd = nh, ln = nl;
                     uint4 cv[2 * WAVE_CONV_MAX];
+                    const uint4 *rp = rowp + r * RUN;
                     const uint4 *np = rowp + (r + 1u < sc.nrows ? r + 1u : 0u) * RUN;
+                    cv[0] = ncv[0];
+                    cv[1] = ncv[1];
+                    // (the further sums of this row: requested now, with the next row's first units)
 #pragma unroll
-                    for (int u = 0; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
-                        cv[u] = ncv[u];
+                    for (int u = 2; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
+                        cv[u] = rp[(5 + u) * NG];
                     }
                     nh = np[0];
                     nl = np[lin_unit];
-#pragma unroll
-                    for (int u = 0; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
-                        ncv[u] = np[(5 + u) * NG];
-                    }
+                    ncv[0] = np[5 * NG];
+                    ncv[1] = np[6 * NG];
                     const std::uint32_t fl = hd.y;
                     const int nk = __builtin_amdgcn_readfirstlane(static_cast<int>(hd.z));
                     // No branches below except wave-uniform ones: an absent linear term reads offset 0
@@ -554,9 +577,16 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
                 tc_prev = tc;
                 ++ns;
             }
+            // The next substep starts from series that are zero but for the state.
+            const double keep = lo < 7 ? (step_ok ? nv : W[lo * L]) : 1.;
             wave_lds_sync();
-            if (step_ok && lo < 7) {
-                W[lo * L] = nv;
+            clear_series();
+            wave_lds_sync();
+            if (lo < 7) {
+                W[lo * L] = keep;
+            }
+            if (lo == 7) {
+                W[sc.one * L] = keep;
             }
             wave_lds_sync();
             if (step_ok) {

@@ -37,11 +37,14 @@ struct wave_plan {
     // (of a workgroup: the objects' series of every wave, then the schedule)
     [[nodiscard]] std::size_t lds_bytes() const
     {
-        return WAVE_LDS_PAD * sizeof(double) + wpb * wave_bytes() + blk_bytes();
+        return wpb * wave_bytes() + blk_bytes();
     }
     [[nodiscard]] unsigned waves_per_cu() const
     {
-        return static_cast<unsigned>(WAVE_LDS_MAX / lds_bytes()) * wpb;
+        // (LDS is handed out in blocks: three workgroups of 53 824 bytes did not share a compute
+        // unit, three of 52 928 did; counted with 2 KB blocks)
+        const std::size_t granted = (lds_bytes() + 2047u) / 2048u * 2048u;
+        return static_cast<unsigned>(WAVE_LDS_MAX / granted) * wpb;
     }
 };
 
