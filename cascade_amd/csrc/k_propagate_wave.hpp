@@ -48,17 +48,18 @@ namespace csc
 struct wave_hdr {
     std::uint32_t dst, flags; // (dst: byte offset)
     std::uint32_t nk; // convolution sums of the ROW (the most of any of its operations)
-    std::uint32_t pad;
+    std::uint32_t weighted; // 1 when a sum of the ROW has weights that depend on n or j (wave_conv: wa, wb)
 };
 struct wave_lin {
     std::uint32_t off, pad; // (no term: offset 0 with coefficient 0)
     double coef;
 };
 // sum over j = jlo .. n - hoff of (n wa + j wb + wc) A[j] B[n - j], as terms jj = j - jlo = 0 .. n - (jlo + hoff):
+// (two units: a, b, wc -- all a plain product needs -- and wa, wb, which a row without weighted sums never reads)
 struct wave_conv {
     std::uint32_t a; // byte offset of A[jlo] | (jlo + hoff) << 20 (no sum: 0xfff << 20)
     std::int32_t b;  // byte offset of B[-jlo]: term jj reads B at b + 8 (n - jj)
-    double wa, wb, wc; // weight of term jj: n wa + jj wb + wc (wc includes jlo wb)
+    double wc, wa, wb; // weight of term jj: n wa + jj wb + wc (wc includes jlo wb)
 };
 enum : std::uint32_t { WF_TIME = 1, WF_DIVN = 2 };
 // WAVE_OBJ_PAD doubles of zeros in front of every object's series (a term beyond the range of a
@@ -92,8 +93,9 @@ template <int CTRL>
 CSC_DEV double dpp_f64(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // (every lane has a source lane under the controls used here: the old value never shows)
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi2, lo2);
 }
 
@@ -138,6 +140,11 @@ CSC_DEV double wave_event_root(const double *gs, double h, int direction, int *f
     return event_first_root<P>(g, h, direction, flags);
 }
 
+// 1 / n as the division would give it (a division costs ~35 instructions, and there were two per order).
+__device__ const double wave_rcp[32] = {0.,      1. / 1,  1. / 2,  1. / 3,  1. / 4,  1. / 5,  1. / 6,  1. / 7,  1. / 8,  1. / 9,  1. / 10,
+                                        1. / 11, 1. / 12, 1. / 13, 1. / 14, 1. / 15, 1. / 16, 1. / 17, 1. / 18, 1. / 19, 1. / 20, 1. / 21,
+                                        1. / 22, 1. / 23, 1. / 24, 1. / 25, 1. / 26, 1. / 27, 1. / 28, 1. / 29, 1. / 30, 1. / 31};
+
 CSC_DEV double u2d(std::uint32_t lo, std::uint32_t hi)
 {
     return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
@@ -156,7 +163,7 @@ struct wave_conv_ctx {
 // a zero on the A side; what they read on the B side (lower slots of the same object, or the
 // zeros in front of its first series) is finite. With 8 lanes the third trip can leave the
 // series (terms 16 .. 23 of 21 coefficients): those lanes are masked.
-template <int NK, int TR, int LPG>
+template <int NK, int TR, int LPG, bool WT>
 CSC_DEV double wave_conv_sums(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_conv_ctx &c, double acc)
 {
     double av[NK][TR], bv[NK][TR];
@@ -171,45 +178,81 @@ CSC_DEV double wave_conv_sums(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_c
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const double wb = u2d(cv[2 * k + 1].x, cv[2 * k + 1].y);
-        double w = fma(c.dsub, wb, fma(c.dn, u2d(cv[2 * k].z, cv[2 * k].w), u2d(cv[2 * k + 1].z, cv[2 * k + 1].w)));
+        const double wc = u2d(cv[2 * k].z, cv[2 * k].w);
+        if constexpr (WT) {
+            const double wb = u2d(cv[2 * k + 1].z, cv[2 * k + 1].w);
+            double w = fma(c.dsub, wb, fma(c.dn, u2d(cv[2 * k + 1].x, cv[2 * k + 1].y), wc));
 #pragma unroll
-        for (int t = 0; t < TR; ++t) {
-            if (LPG * (t + 1) > P_SERIES) {
-                const int lim = c.n - static_cast<int>(cv[2 * k].x >> 20) - c.sub;
-                const double p = fma(w * av[k][t], bv[k][t], acc);
-                acc = lim >= LPG * t ? p : acc;
-            } else {
-                acc = fma(w * av[k][t], bv[k][t], acc);
+            for (int t = 0; t < TR; ++t) {
+                if (LPG * (t + 1) > P_SERIES) {
+                    const int lim = c.n - static_cast<int>(cv[2 * k].x >> 20) - c.sub;
+                    const double p = fma(w * av[k][t], bv[k][t], acc);
+                    acc = lim >= LPG * t ? p : acc;
+                } else {
+                    acc = fma(w * av[k][t], bv[k][t], acc);
+                }
+                w = fma(static_cast<double>(LPG), wb, w);
             }
-            w = fma(static_cast<double>(LPG), wb, w);
+        } else {
+            // (constant weight: the plain sum of products, scaled once)
+            double sk = 0.;
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                if (LPG * (t + 1) > P_SERIES) {
+                    const int lim = c.n - static_cast<int>(cv[2 * k].x >> 20) - c.sub;
+                    const double p = fma(av[k][t], bv[k][t], sk);
+                    sk = lim >= LPG * t ? p : sk;
+                } else {
+                    sk = fma(av[k][t], bv[k][t], sk);
+                }
+            }
+            acc = fma(wc, sk, acc);
         }
     }
     return acc;
 }
 
-template <int NK, int LPG>
+template <int NK, int LPG, bool WT>
 CSC_DEV double wave_conv_trips(const uint4 (&cv)[2 * WAVE_CONV_MAX], const wave_conv_ctx &c, double acc, int trips)
 {
     switch (trips) {
         case 1:
-            return wave_conv_sums<NK, 1, LPG>(cv, c, acc);
+            return wave_conv_sums<NK, 1, LPG, WT>(cv, c, acc);
         case 2:
-            return wave_conv_sums<NK, 2, LPG>(cv, c, acc);
+            return wave_conv_sums<NK, 2, LPG, WT>(cv, c, acc);
         case 3:
-            return wave_conv_sums<NK, 3, LPG>(cv, c, acc);
+            return wave_conv_sums<NK, 3, LPG, WT>(cv, c, acc);
         // (in two parts it was slower: 14.5 against 13.4 ms for the default dynamics)
         case 4:
             if constexpr (LPG < 8) {
-                return wave_conv_sums<NK, 4, LPG>(cv, c, acc);
+                return wave_conv_sums<NK, 4, LPG, WT>(cv, c, acc);
             }
             return acc;
         default:
             if constexpr (LPG < 8) {
-                return wave_conv_sums<NK, 5, LPG>(cv, c, acc);
+                return wave_conv_sums<NK, 5, LPG, WT>(cv, c, acc);
             }
             return acc;
     }
+}
+
+// The sums of a row: its units beyond the first (which came with the previous row) are requested
+// here, the second unit of a sum only when the row has weighted sums.
+template <int NK, int LPG>
+CSC_DEV double wave_row_sums(uint4 (&cv)[2 * WAVE_CONV_MAX], const uint4 *rp, int ng, bool weighted, const wave_conv_ctx &c, double acc, int trips)
+{
+#pragma unroll
+    for (int k = 1; k < NK; ++k) {
+        cv[2 * k] = rp[(5 + 2 * k) * ng];
+    }
+    if (weighted) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            cv[2 * k + 1] = rp[(6 + 2 * k) * ng];
+        }
+        return wave_conv_trips<NK, LPG, true>(cv, c, acc, trips);
+    }
+    return wave_conv_trips<NK, LPG, false>(cv, c, acc, trips);
 }
 
 // Sum over the LPG lanes of a group (every lane gets the result).
@@ -311,34 +354,30 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
 
             // ---- orders 0 .. P - 1 of every operation; order n of the right-hand side gives order n + 1 of the state ----
             for (int n = 0; n < P; ++n) {
-                const double dn = static_cast<double>(n), rn = n > 0 ? 1. / dn : 1.;
-                const int trips = (n + LPG) / LPG;
+                static_assert(P < 31, "wave_rcp");
+                const double dn = static_cast<double>(n), rn = n > 0 ? wave_rcp[n] : 1.;
+                const int trips = __builtin_amdgcn_readfirstlane((n + LPG) / LPG);
+                const bool order0 = __builtin_amdgcn_readfirstlane(n) == 0;
                 const char *Wn = Wb + 8 * n;      // + offset of a series: its order n
                 const char *Wnb = Wn - 8 * sub;   // ... its order n - sub
                 uint4 nh = rowp[0], nl = rowp[lin_unit];
-                uint4 ncv[2] = {rowp[5 * NG], rowp[6 * NG]};
+                uint4 ncv = rowp[5 * NG];
                 for (std::uint32_t r = 0; r < sc.nrows; ++r) {
-                    // (the next row's header, linear term and sums are requested before this row's work starts)
+                    // (the next row's header, linear term and first sum are requested before this row's work starts)
                     const uint4 hd = nh, ln = nl;
                     uint4 cv[2 * WAVE_CONV_MAX];
                     const uint4 *rp = rowp + r * RUN;
                     const uint4 *np = rowp + (r + 1u < sc.nrows ? r + 1u : 0u) * RUN;
-                    cv[0] = ncv[0];
-                    cv[1] = ncv[1];
-                    // (the further sums of this row: requested now, with the next row's first units)
-#pragma unroll
-                    for (int u = 2; u < 2 * static_cast<int>(WAVE_CONV_MAX); ++u) {
-                        cv[u] = rp[(5 + u) * NG];
-                    }
+                    cv[0] = ncv;
                     nh = np[0];
                     nl = np[lin_unit];
-                    ncv[0] = np[5 * NG];
-                    ncv[1] = np[6 * NG];
+                    ncv = np[5 * NG];
                     const std::uint32_t fl = hd.y;
                     const int nk = __builtin_amdgcn_readfirstlane(static_cast<int>(hd.z));
+                    const bool weighted = __builtin_amdgcn_readfirstlane(static_cast<int>(hd.w)) != 0;
                     // No branches below except wave-uniform ones: an absent linear term reads offset 0
                     // with coefficient 0, an absent sum has an empty range, an empty place in a row
-                    // writes to the spare slot behind the series, all 8 lanes store the (same) result.
+                    // writes to the spare slot behind the series, all lanes of a group store the (same) result.
                     const double pmv = pm[r * NG + grp]; // (order 0 writes it below and does not use it)
                     double acc = u2d(ln.z, ln.w) * *reinterpret_cast<const double *>(Wn + ln.x);
                     if constexpr (LPG == 8) {
@@ -349,22 +388,22 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
                     const wave_conv_ctx cc{Ws, Wnb, n, sub, dn, dsub};
                     switch (nk) {
                         case 1:
-                            acc = wave_conv_trips<1, LPG>(cv, cc, acc, trips);
+                            acc = wave_row_sums<1, LPG>(cv, rp, NG, weighted, cc, acc, trips);
                             break;
                         case 2:
-                            acc = wave_conv_trips<2, LPG>(cv, cc, acc, trips);
+                            acc = wave_row_sums<2, LPG>(cv, rp, NG, weighted, cc, acc, trips);
                             break;
                         case 3:
-                            acc = wave_conv_trips<3, LPG>(cv, cc, acc, trips);
+                            acc = wave_row_sums<3, LPG>(cv, rp, NG, weighted, cc, acc, trips);
                             break;
                         case 4:
-                            acc = wave_conv_trips<4, LPG>(cv, cc, acc, trips);
+                            acc = wave_row_sums<4, LPG>(cv, rp, NG, weighted, cc, acc, trips);
                             break;
                         default: // (a row without sums)
                             break;
                     }
                     acc = group_sum<LPG>(acc);
-                    if (n == 0) {
+                    if (order0) {
                         // The functions themselves, and the order-independent factor of the recurrence.
                         const wave_op0 o = ops0[static_cast<std::size_t>(r) * NG];
                         const double sv = o.par >= 0 ? pars[o.par] : o.c;
@@ -415,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm
                     wave_lds_sync();
                 }
                 if (lo < 7) {
-                    W[lo * L + n + 1] = W[sc.rhs[lo] * L + n] * (1. / static_cast<double>(n + 1));
+                    W[lo * L + n + 1] = W[sc.rhs[lo] * L + n] * wave_rcp[n + 1];
                 }
                 wave_lds_sync();
             }
