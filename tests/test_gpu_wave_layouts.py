@@ -1,0 +1,83 @@
+"""Every layout of k_propagate_wave (groups per object x lanes per operation, with and without
+terminal events: 14 kernel instances of which the library's own choice exercises four) against the
+one-lane-per-object interpreter on the same dynamics: same outcomes, interrupt info, substep
+counts, broad-phase pair counts and conjunctions; states within 1e-9 of the vector's scale."""
+import numpy as np
+import pytest
+
+from _tol import states_close
+
+pytestmark = pytest.mark.gpu
+LAYOUTS = [(1, 8), (2, 8), (4, 8), (8, 8), (2, 4), (4, 4), (8, 4)]
+
+
+def _run(monkeypatch, wave, ng, lpg, events, which):
+    from cascade_amd import dynamics as D
+    from cascade_amd import sim
+    from cascade_amd.workloads import haumea_dynamics, haumea_ring, leo_si_population
+
+    monkeypatch.setenv("CASCADE_WAVE", "1" if wave else "0")
+    if wave:
+        monkeypatch.setenv("CASCADE_WAVE_NG", str(ng))
+        monkeypatch.setenv("CASCADE_WAVE_LPG", str(lpg))
+    if which == "haumea":
+        dyn, k = haumea_dynamics()
+        kw = dict(n_par_ct=2)
+        if events:
+            kw.update(reentry_radius=[k["ra"], k["rb"], k["rc"]], exit_radius=k["a_s"] * 10)
+        s = sim(haumea_ring(1500), 5000.0, dyn=dyn, **kw)
+    else:
+        dyn = D.simple_earth()
+        n = 1203  # (not a multiple of the objects of a workgroup: the last wave has lanes without an object)
+        st, bstar = leo_si_population(n, seed=7)
+        st[:, 6] *= 50.0
+        s = sim(st, 185.5663, dyn=dyn, pars=bstar.copy(), n_par_ct=5, conj_thresh=5000.0,
+                reentry_radius=(6378136.3 + 150e3) if events else 0.0)
+        s.time = 2.5e8
+    from cascade_amd import _capi
+
+    ctx = _capi.Context.from_handle(s._hip_context)
+    ctx.profile(True)
+    ctx.profile_reset()
+    out = []
+    for _ in range(3):
+        oc = s.step()
+        ii = s.interrupt_info
+        out.append((oc.name, ii, s.time, s.state.copy(), s.last_bp_pairs, s.last_total_substeps))
+        if oc.name in ("reentry", "exit"):
+            s.remove_particles([ii])
+        elif oc.name == "collision":
+            s.remove_particles(list(ii))
+    conj = s.conjunctions.copy()
+    # (a layout that does not fit falls back on the interpreter silently: the comparison would be with itself)
+    kernels = set(ctx.profile_get())
+    assert ("k_propagate_wave" in kernels) == bool(wave), kernels
+    return out, conj
+
+
+@pytest.fixture(scope="module")
+def interp():
+    return {}
+
+
+@pytest.mark.parametrize("which", ["default", "haumea"])
+@pytest.mark.parametrize("events", [True, False])
+@pytest.mark.parametrize("ng,lpg", LAYOUTS)
+def test_layout_matches_the_interpreter(ng, lpg, events, which, interp, monkeypatch):
+    key = (which, events)
+    if key not in interp:
+        interp[key] = _run(monkeypatch, False, 0, 0, events, which)
+    want, wconj = interp[key]
+    got, gconj = _run(monkeypatch, True, ng, lpg, events, which)
+    for (gn, gi, gt, gs, gp, gsub), (wn, wi, wt, ws, wp, wsub) in zip(got, want):
+        assert gn == wn
+        if isinstance(wi, (tuple, list)) and len(wi) == 2 and isinstance(wi[1], float):
+            assert gi[0] == wi[0] and abs(gi[1] - wi[1]) <= 1e-9 * max(1.0, abs(wi[1]))
+        else:
+            assert gi == wi
+        assert abs(gt - wt) <= 1e-9 * max(1.0, abs(wt))
+        assert gs.shape == ws.shape and states_close(gs, ws, 1e-9)
+        assert gp == wp and gsub == wsub
+    assert len(gconj) == len(wconj)
+    if len(wconj):
+        assert np.array_equal(gconj["i"], wconj["i"]) and np.array_equal(gconj["j"], wconj["j"])
