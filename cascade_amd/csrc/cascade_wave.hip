@@ -721,7 +721,7 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
             p.lpg = lpg;
             // Waves per workgroup: what puts the most waves on a compute unit (fewer when equal).
             unsigned best_w = 0;
-            for (std::uint32_t w = 1; w <= 4u; ++w) {
+            for (std::uint32_t w = 1; w <= WAVE_WPB_MAX; ++w) {
                 p.wpb = w;
                 if (p.lds_bytes() <= WAVE_LDS_MAX && p.waves_per_cu() > best_w) {
                     best_w = p.waves_per_cu();
@@ -730,7 +730,7 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
             if (best_w == 0u) {
                 continue;
             }
-            for (std::uint32_t w = 1; w <= 4u; ++w) {
+            for (std::uint32_t w = 1; w <= WAVE_WPB_MAX; ++w) {
                 p.wpb = w;
                 if (p.lds_bytes() <= WAVE_LDS_MAX && p.waves_per_cu() == best_w) {
                     break;

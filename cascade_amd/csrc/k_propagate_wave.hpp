@@ -66,6 +66,8 @@ enum : std::uint32_t { WF_TIME = 1, WF_DIVN = 2 };
 // sum reads up to 21 doubles before a series); P_SERIES: coefficients of a series at order 20.
 constexpr std::uint32_t WAVE_LIN_MAX = 4, WAVE_CONV_MAX = 4, WAVE_OBJ_PAD = 24;
 constexpr int P_SERIES = 21;
+// Waves of a workgroup at most (they share the schedule in LDS; 7 x 20 KB of series + 13 KB of schedule fill a compute unit).
+constexpr std::uint32_t WAVE_WPB_MAX = 8;
 static_assert(sizeof(wave_hdr) == 16 && sizeof(wave_lin) == 16 && sizeof(wave_conv) == 32, "schedule layout");
 
 // Order 0 of one scheduled operation, 32 bytes: what to do with the sums of order 0, and what to leave in pm.
@@ -267,10 +269,10 @@ CSC_DEV double group_sum(double v)
     return v;
 }
 
-// A workgroup is 1 to 4 waves that share nothing but the copy of the schedule in LDS: after the
+// A workgroup is 1 to 8 waves that share nothing but the copy of the schedule in LDS: after the
 // copy every wave works through its own objects and synchronises with itself only.
 template <int P, int NG, int LPG, bool EVENTS>
-__global__ __launch_bounds__(256, 2) void k_propagate_wave(const prop_params prm, const wave_sched sc)
+__global__ __launch_bounds__(64 * WAVE_WPB_MAX, 2) void k_propagate_wave(const prop_params prm, const wave_sched sc)
 {
     extern __shared__ double lds[];
     constexpr int L = P + 1;
