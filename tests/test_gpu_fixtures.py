@@ -195,3 +195,47 @@ def test_shells_2m_properties():
             assert np.max(np.abs(e1 - e0)) < 1e-12
     assert attempts[0] > 1, "the first superstep should overflow its guessed capacities"
     assert len(a.conjunctions) == len(b.conjunctions)
+
+
+def test_shells_10m_properties():
+    """BASELINE configs[3] at its full size (10 000 000 objects, n_par_ct = 2, conj_thresh = 5 km):
+    two supersteps with the records left on the device, then the size-independent properties of
+    the ~2.8e7 conjunction records -- per superstep sorted by time and inside the superstep, i < j,
+    dist < conj_thresh and equal to the distance of the two recorded states, recorded states on the
+    two Keplerian orbits -- and the device store's count equal to what the list then holds."""
+    from cascade_amd import _capi, sim
+    from cascade_amd.workloads import leo_shells
+
+    n, thr = 10_000_000, 7.8e-4
+    st = leo_shells(n, seed=42)
+    s = sim(st, 0.02, n_par_ct=2, conj_thresh=thr, min_coll_radius=float("inf"))
+    s.host_sync = False
+    cx = _capi.Context.from_handle(s._hip_context)
+    times = [s.time]
+    for _ in range(2):
+        assert s.step().name == "success"
+        times.append(s.time)
+    pending = int(cx.L.csc_conj_store_size(cx.h))
+    assert pending > 10_000_000, "the records of both supersteps wait on the device"
+    conj = s.conjunctions
+    assert len(conj) == pending and cx.L.csc_conj_store_size(cx.h) == 0
+    seg = np.asarray(s._conj_segments, dtype=np.int64)[:, 1]  # (superstep, records appended by it)
+    assert seg.sum() == len(conj) and len(seg) == 2
+    lo = 0
+    for k, cnt in enumerate(seg):
+        c = conj[lo : lo + cnt]
+        lo += cnt
+        assert cnt > 5_000_000
+        assert np.all(np.diff(c["time"]) >= 0)
+        assert c["time"][0] >= times[k] and c["time"][-1] < times[k + 1]
+    assert np.all(conj["i"] < conj["j"]) and conj["j"].max() < n
+    assert np.all(conj["dist"] < thr)
+    # (the rest on every 16th record: 1.8e6 of them)
+    c = conj[::16]
+    d = np.linalg.norm(c["state_i"][:, :3] - c["state_j"][:, :3], axis=1)
+    assert np.all(np.abs(d - c["dist"]) <= 1e-12)
+    for f, idx in (("state_i", c["i"]), ("state_j", c["j"])):
+        s0 = st[idx.astype(np.int64)]
+        e0 = 0.5 * np.sum(s0[:, 3:6] ** 2, axis=1) - 1.0 / np.linalg.norm(s0[:, :3], axis=1)
+        e1 = 0.5 * np.sum(c[f][:, 3:6] ** 2, axis=1) - 1.0 / np.linalg.norm(c[f][:, :3], axis=1)
+        assert np.max(np.abs(e1 - e0)) < 1e-12
