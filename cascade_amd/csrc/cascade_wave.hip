@@ -870,9 +870,15 @@ hipError_t wave_launch(const wave_plan &plan, const std::uint32_t *d_blk, const 
                        hipStream_t stream)
 {
     const int ng = static_cast<int>(plan.ng), lpg = static_cast<int>(plan.lpg);
-    const unsigned opb = 64u / (plan.lpg * plan.ng) * plan.wpb; // objects per workgroup
-    const dim3 grid(static_cast<unsigned>((static_cast<std::uint64_t>(prm.n) + opb - 1u) / opb)), block(64u * plan.wpb);
-    const std::size_t lds_bytes = plan.lds_bytes();
+    // Waves per workgroup: the plan's (what fills a compute unit), fewer when there would not be a
+    // workgroup for each of the 256 compute units (1000 objects are 500 waves: 72 workgroups of 7
+    // would leave two thirds of the GPU idle).
+    const unsigned opw = 64u / (plan.lpg * plan.ng);
+    const std::uint64_t waves = (static_cast<std::uint64_t>(prm.n) + opw - 1u) / opw;
+    const unsigned wpb = static_cast<unsigned>(std::max<std::uint64_t>(1u, std::min<std::uint64_t>(plan.wpb, waves / 256u)));
+    const unsigned opb = opw * wpb; // objects per workgroup
+    const dim3 grid(static_cast<unsigned>((static_cast<std::uint64_t>(prm.n) + opb - 1u) / opb)), block(64u * wpb);
+    const std::size_t lds_bytes = wpb * plan.wave_bytes() + plan.blk_bytes();
     wave_sched sc{};
     sc.blk = reinterpret_cast<const uint4 *>(d_blk);
     sc.ops0 = d_ops0;
