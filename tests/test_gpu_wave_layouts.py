@@ -81,3 +81,38 @@ def test_layout_matches_the_interpreter(ng, lpg, events, which, interp, monkeypa
     assert len(gconj) == len(wconj)
     if len(wconj):
         assert np.array_equal(gconj["i"], wconj["i"]) and np.array_equal(gconj["j"], wconj["j"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_dynamics_match_the_interpreter(seed, monkeypatch):
+    """The random right-hand sides of tests/test_wave_plan_fuzz.py (every operation kind, constants
+    and runtime parameters on either side, sums larger than an operation holds, time dependence) on
+    the GPU: the fused kernel against the one-lane interpreter of the plain tape."""
+    from cascade_amd import _capi, sim
+    from cascade_amd.workloads import random_leo_pop_kep
+    from test_wave_plan_fuzz import _random_dynamics
+
+    dyn = _random_dynamics(seed)
+    npars = dyn.tape["npars"]
+    n = 777
+    st = random_leo_pop_kep(n, seed=seed)
+    pars = np.random.default_rng(seed).uniform(0.5, 1.5, (n, max(1, npars)))[:, :npars].copy()
+    res = []
+    for wave in (0, 1):
+        monkeypatch.setenv("CASCADE_WAVE", str(wave))
+        kw = dict(dyn=dyn, n_par_ct=3, conj_thresh=1e-2, min_coll_radius=float("inf"))
+        if npars:
+            kw["pars"] = pars
+        s = sim(st.copy(), 0.23, **kw)
+        s.time = 0.37
+        ctx = _capi.Context.from_handle(s._hip_context)
+        ctx.profile(True)
+        ctx.profile_reset()
+        for _ in range(3):
+            assert s.step().name == "success"
+        assert ("k_propagate_wave" in set(ctx.profile_get())) == bool(wave)
+        res.append((s.state.copy(), s.time, s.last_bp_pairs, s.last_total_substeps, s.conjunctions.copy()))
+    (s0, t0, p0, n0, c0), (s1, t1, p1, n1, c1) = res
+    assert t0 == t1 and n0 == n1 and p0 == p1
+    assert states_close(s1, s0, 1e-9)
+    assert len(c0) == len(c1) and np.array_equal(c0["i"], c1["i"]) and np.array_equal(c0["j"], c1["j"])
