@@ -27,6 +27,42 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from cascade_amd import _capi
 
+    if mode == "rcclhelpers":
+        # The three exchange helpers on DEVICE memory through the nccl (RCCL) backend, with as many
+        # ranks as there are: what a one-GPU box can execute of the production path (one rank:
+        # every collective returns the rank's own bytes, but tensor types, sizes, the
+        # __cuda_array_interface__ views and the stream handling are the ones N ranks use).
+        import torch
+
+        from cascade_amd.parallel import make_device_alltoall, make_device_gather, make_summary_exchange
+
+        assert backend == "nccl"
+        ex = make_summary_exchange()
+        for step in range(3):
+            out = ex(np.arange(6, dtype=np.int64) + 10 * rank + step)
+            assert out.shape == (world, 6)
+            for r in range(world):
+                assert np.array_equal(out[r], np.arange(6, dtype=np.int64) + 10 * r + step)
+        gather, a2a = make_device_gather(), make_device_alltoall()
+        nb = 1 << 20
+        src = torch.randint(0, 255, (nb,), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros(nb * world, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gather(src.data_ptr(), dst.data_ptr(), nb)
+        assert torch.equal(dst[rank * nb : (rank + 1) * nb], src)
+        # all-to-all: rank r receives segment r of every sender (ragged segments, one of them empty when world > 1)
+        seg = [1000 * (r + 1) if (r != 1 or world == 1) else 0 for r in range(world)]
+        send = torch.randint(0, 255, (sum(seg),), dtype=torch.uint8, device="cuda")
+        recv = torch.zeros(max(seg[rank], 1) * world, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        if seg[rank]:
+            a2a(send.data_ptr(), recv.data_ptr(), seg, seg[rank])
+            off = sum(seg[:rank])
+            assert torch.equal(recv[rank * seg[rank] : (rank + 1) * seg[rank]], send[off : off + seg[rank]])
+        dist.barrier()
+        print("rcclhelpers ok")
+        dist.destroy_process_group()
+        return
     if mode == "exchange":
         from cascade_amd.parallel import make_summary_exchange, merge_conjunctions
 

@@ -73,6 +73,14 @@ def _gpus():
 
 
 @pytest.mark.gpu
+def test_rccl_exchange_helpers():
+    """The exchange helpers of cascade_amd.parallel on device memory through the nccl (RCCL)
+    backend, with every GPU there is (one rank on a one-GPU box: RCCL initialises, the device
+    tensors, views of the simulation's memory and collectives are the production ones)."""
+    _run_world("rcclhelpers", world=max(1, min(_gpus(), 8)), backend="nccl", timeout=180)
+
+
+@pytest.mark.gpu
 def test_sharded_sim_rccl():
     """The production backend: one GPU per rank, RCCL all-gathers on device tensors. Needs at
     least two GPUs; skipped on a one-GPU box (where the gloo tests above cover the logic)."""
