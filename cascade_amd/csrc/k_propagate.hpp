@@ -840,11 +840,31 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
             if (h > 0.) {
                 double ev_t = 0.;
                 std::uint32_t idx = 0;
+                // Where the object can be during the step, from the series of r: r0 -+ sum |r_n| h^n.
+                // The event polynomials (700 multiply-adds each) are built only where that bound
+                // reaches the surface, with a margin of 1e-9 for what separates the series of r
+                // from the norm of the truncated position polynomials; a NaN keeps the search.
+                double rlo, rhi;
+                {
+                    double sabs = fabs(t.r[P]);
+#pragma unroll
+                    for (int o = P - 1; o >= 1; --o) {
+                        sabs = fma(sabs, h, fabs(t.r[o]));
+                    }
+                    const double dev = sabs * h;
+                    rlo = t.r[0] - dev;
+                    rhi = t.r[0] + dev;
+                }
+                const double re_kmin = dmin(prm.re_k[0], dmin(prm.re_k[1], prm.re_k[2]));
+                const bool may_exit = !(rhi * rhi < prm.exit_c0 * (1. - 1e-9));
+                const bool may_reenter = !(rlo > 0. && re_kmin > 0. && re_kmin * (rlo * rlo) > prm.re_c0 * (1. + 1e-9));
                 if (prm.has_exit) {
                     double g[P + 1];
-                    ev_poly_order<P, 0>::run(t, g, 1., 1., 1.);
-                    g[0] -= prm.exit_c0;
-                    if (!fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
+                    if (may_exit) {
+                        ev_poly_order<P, 0>::run(t, g, 1., 1., 1.);
+                        g[0] -= prm.exit_c0;
+                    }
+                    if (may_exit && !fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
                         const double rt = event_first_root<P>(g, h, 1, &flags);
                         if (rt >= 0.) {
                             ev_found = true;
@@ -856,9 +876,11 @@ CSC_DEV void propagate_object(const prop_params &prm, const std::uint32_t lane_k
                 }
                 if (prm.has_reentry) {
                     double g[P + 1];
-                    ev_poly_order<P, 0>::run(t, g, prm.re_k[0], prm.re_k[1], prm.re_k[2]);
-                    g[0] -= prm.re_c0;
-                    if (!fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
+                    if (may_reenter) {
+                        ev_poly_order<P, 0>::run(t, g, prm.re_k[0], prm.re_k[1], prm.re_k[2]);
+                        g[0] -= prm.re_c0;
+                    }
+                    if (may_reenter && !fex_excluded<P>(g, h) && !descartes_no_root<P>(g, h)) {
                         const double rt = event_first_root<P>(g, h, -1, &flags);
                         if (rt >= 0. && (!ev_found || rt < ev_t)) {
                             ev_found = true;
