@@ -138,6 +138,8 @@ SYMBOLS = {
     "csc_propagate_range": (_i32, [_vp, C.POINTER(PropCfg), _u32, _u32, _u32] + [_vp] * 10),
     "csc_propagate_range_rows": (_i32, [_vp, C.POINTER(PropCfg), _u32, _u32, _u32] + [_vp] * 10 + [_u32]),
     "csc_wave_plan_eval": (_i32, [_vp, _u32, _u32, _vp, _i32, _u32, _vp, _vp, C.c_double, _vp, _vp]),
+    "csc_wave_emit_source": (_u64, [_vp, _u32, _u32, _vp, _u32, _i32, _vp, _u64, _vp]),
+    "csc_wave_would_run": (_i32, [_vp, C.POINTER(PropCfg), _u32]),
     "csc_shard_record_bytes": (_sz, [_u32]),
     "csc_shard_pack": (_i32, [_vp, _u32, _u32, _u32, _u32] + [_vp] * 10),
     "csc_shard_unpack": (_i32, [_vp, _u32, _u32] + [_vp] * 10),

@@ -143,6 +143,10 @@ struct csc_ctx {
     std::vector<csc_tape_op> wave_tape;
     csc::wave_plan wave_plan;
     bool wave_fits = false;
+    // ... and, when the schedule is one of the compiled tapes (cascade_tapes.hip), its plan with one operation per row.
+    csc::wave_plan wave_plan1;
+    int wave_compiled = 0;
+    bool wave_uploaded = false; // (the interpreted schedule is on the device)
     int wave_mode = -1;
     bool pass1_wave = false; // the last pass 1 ran k_propagate_wave: the store pass then does too (same substeps)
     float4 *na_scratch = nullptr;       // device address of `scratch` on this context's device
@@ -1324,16 +1328,24 @@ int csc_check_flags(csc_ctx *ctx)
 // One object over several lanes, series in LDS (k_propagate_wave.hpp): every right-hand side that
 // comes with its tape, except plain Kepler (order 20). Schedules the tape when it is new, launches
 // the kernel and sets `launched`; leaves it false when the kernel does not apply.
-static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::prop_params &p, bool events, bool &launched)
+// The tagged built-ins (Kepler + J2 + drag ...) have hand-unrolled kernels, one object per lane, that
+// win once the population fills the GPU with them (64 objects per wave); below that a COMPILED tape
+// -- 8 objects per wave -- is the faster one (J2 + drag, 19 647 objects: 3.6 against 5.4 ms; 1M: 44.8 against 39.7).
+constexpr uint32_t WAVE_TAGGED_MAX_N = 49152;
+
+// Schedules the tape when it is new and says what would run it: 0 the one-lane kernels, 1 the
+// interpreted rows of k_propagate_wave, 2 one of its compiled tapes.
+static int wave_select(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n_total, bool *fresh_out = nullptr)
 {
-    launched = false;
+    if (fresh_out) {
+        *fresh_out = false;
+    }
     if (ctx->wave_mode < 0) {
         const char *e = std::getenv("CASCADE_WAVE");
         ctx->wave_mode = (e && std::atoi(e) == 0) ? 0 : 1;
     }
-    // (the hand-unrolled kernels of the built-in dynamics are faster than this one)
-    if (ctx->wave_mode != 1 || cfg->order != 20u || cfg->tape == nullptr || cfg->dyn_kind != CSC_DYN_TAPE) {
-        return CSC_OK;
+    if (ctx->wave_mode != 1 || cfg->order != 20u || cfg->tape == nullptr || cfg->tape_nops == 0u) {
+        return 0;
     }
     static_assert(sizeof(csc_tape_op) == sizeof(csc::tape_op), "tape layout");
     const size_t bytes = static_cast<size_t>(cfg->tape_nops) * sizeof(csc_tape_op);
@@ -1344,22 +1356,67 @@ static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::pro
         ctx->wave_tape.assign(cfg->tape, cfg->tape + cfg->tape_nops);
         ctx->wave_fits = csc::wave_build_plan(reinterpret_cast<const csc::tape_op *>(cfg->tape), cfg->tape_nops, cfg->tape_nslots,
                                               cfg->tape_rhs, 0, cfg->order, ctx->wave_plan);
+        ctx->wave_compiled = 0;
+        ctx->wave_uploaded = false;
+        const char *ce = std::getenv("CASCADE_WAVE_COMPILED");
+        if (!(ce && std::atoi(ce) == 0) && !std::getenv("CASCADE_WAVE_NG")
+            && csc::wave_build_plan(reinterpret_cast<const csc::tape_op *>(cfg->tape), cfg->tape_nops, cfg->tape_nslots, cfg->tape_rhs, 1,
+                                    cfg->order, ctx->wave_plan1)) {
+            // (two waves per compute unit at least, counted in 2 KB blocks of LDS as in wave_plan::waves_per_cu)
+            const size_t granted = (ctx->wave_plan1.wave_bytes() + 2047u) / 2048u * 2048u;
+            if (csc::WAVE_LDS_MAX / granted >= 2u) {
+                ctx->wave_compiled = csc::wave_compiled_lookup(csc::wave_plan_hash(ctx->wave_plan1));
+            }
+        }
+        if (std::getenv("CASCADE_WAVE_DEBUG")) {
+            std::fprintf(stderr, "[wave] compiled tape: %d\n", ctx->wave_compiled);
+        }
+        if (fresh_out) {
+            *fresh_out = true;
+        }
     }
-    const csc::wave_plan &wp = ctx->wave_plan;
+    if (cfg->dyn_kind != CSC_DYN_TAPE) {
+        return (ctx->wave_compiled != 0 && cfg->dyn_kind == (CSC_DYN_J2 | CSC_DYN_DRAG) && n_total <= WAVE_TAGGED_MAX_N) ? 2 : 0;
+    }
+    if (ctx->wave_compiled != 0) {
+        return 2;
+    }
     // Two waves per compute unit at least: with less, the one-lane-per-object interpreter with its
     // global workspace is the faster one.
-    if (!ctx->wave_fits || (wp.waves_per_cu() < 2u && !std::getenv("CASCADE_WAVE_NG"))) {
+    if (!ctx->wave_fits || (ctx->wave_plan.waves_per_cu() < 2u && !std::getenv("CASCADE_WAVE_NG"))) {
         if (fresh && std::getenv("CASCADE_WAVE_DEBUG")) {
             std::fprintf(stderr, "[wave] not used: %s\n", ctx->wave_fits ? "fewer than two waves per compute unit" : "the tape has no schedule");
         }
+        return 0;
+    }
+    return 1;
+}
+
+static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::prop_params &p, bool events, bool &launched)
+{
+    launched = false;
+    const int how = wave_select(ctx, cfg, p.n_total != 0u ? p.n_total : p.n);
+    if (how == 0) {
         return CSC_OK;
     }
+    if (how == 2) {
+        hipError_t crc = hipSuccess;
+        KT(p.nsub_in ? "k_propagate_wave_store" : "k_propagate_wave",
+           crc = csc::wave_launch_compiled(ctx->wave_compiled, ctx->wave_plan1, events, p, ctx->stream));
+        if (crc != hipSuccess) {
+            return ctx->fail(crc, "k_propagate_wave (compiled tape) launch");
+        }
+        launched = true;
+        return CSC_OK;
+    }
+    const csc::wave_plan &wp = ctx->wave_plan;
     CSC_BUF(d_wblk, uint32_t, "wave_blk", wp.blk.size());
     CSC_BUF(d_wops0, csc::wave_op0, "wave_ops0", wp.ops0.size());
-    if (fresh) {
+    if (!ctx->wave_uploaded) {
         CSC_HIP(hipMemcpyAsync(d_wblk, wp.blk.data(), wp.blk_bytes(), hipMemcpyHostToDevice, ctx->stream));
         CSC_HIP(hipMemcpyAsync(d_wops0, wp.ops0.data(), wp.ops0.size() * sizeof(csc::wave_op0), hipMemcpyHostToDevice, ctx->stream));
         CSC_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->wave_uploaded = true;
     }
     hipError_t lrc = hipSuccess;
     KT(p.nsub_in ? "k_propagate_wave_store" : "k_propagate_wave", lrc = csc::wave_launch(wp, d_wblk, d_wops0, events, p, ctx->stream));
@@ -1615,6 +1672,17 @@ int csc_propagate_range_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, 
     CSC_BUF(d_tco, double, "range_tcoords", rows * 2u);
     return propagate_impl(ctx, cfg, n, d_state, d_nsub, d_status, d_ev_idx, d_ev_time, d_nf_last_t, d_final_state, d_lbs,
                           d_ubs, d_recs, row_cap, d_row, d_xyz, d_vr, d_tco, first, count);
+}
+
+int csc_wave_would_run(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n)
+{
+    if (ctx == nullptr || cfg == nullptr) {
+        return 0;
+    }
+    if (check_cfg(ctx, cfg) != CSC_OK) {
+        return 0;
+    }
+    return wave_select(ctx, cfg, n);
 }
 
 int csc_propagate_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, const double *d_state, uint32_t *d_nsub,

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "wave_api.hpp"
 
@@ -446,7 +447,8 @@ void put_unit(std::vector<std::uint32_t> &blk, std::size_t unit, const void *src
 
 // Rows by list scheduling: an operation is ready when everything it reads at the same order is
 // in an earlier row; among the ready ones those with the longest chain behind them go first.
-std::vector<std::vector<std::uint32_t>> schedule(const std::vector<sched_item> &items, std::uint32_t nslots, int ng, std::uint32_t &depth)
+std::vector<std::vector<std::uint32_t>> schedule(const std::vector<sched_item> &items, std::uint32_t nslots, int ng, std::uint32_t &depth,
+                                                 std::vector<std::uint32_t> &levels)
 {
     const std::size_t n = items.size();
     std::vector<std::int32_t> prod(nslots + 1u, -1);
@@ -477,6 +479,7 @@ std::vector<std::vector<std::uint32_t>> schedule(const std::vector<sched_item> &
         }
         depth = std::max(depth, lvl[i]);
     }
+    levels = lvl;
     std::vector<char> wt(n, 0);
     for (std::size_t i = 0; i < n; ++i) {
         for (std::uint32_t k = 0; k < items[i].nk; ++k) {
@@ -670,7 +673,8 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
             continue;
         }
         std::uint32_t depth = 0;
-        const auto rows = schedule(items, nslots_new, ng, depth);
+        std::vector<std::uint32_t> levels;
+        const auto rows = schedule(items, nslots_new, ng, depth, levels);
         const std::uint32_t kp = WAVE_CONV_MAX; // (the kernel requests every unit of a row, used or not)
         wave_plan p = out;
         p.ng = static_cast<std::uint32_t>(ng);
@@ -681,8 +685,18 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
         p.row_units = 1u + WAVE_LIN_MAX + 2u * kp;
         // (zeros in front, the series and a spare one, one factor per place of a row, the event polynomial)
         p.obj_doubles = (WAVE_OBJ_PAD + (nslots_new + 1u) * L + p.nrows * p.ng + L + 2u) & ~1u;
+        if (ng == 1) {
+            // Eight objects per wave read the same offsets of their own series in one instruction, 16
+            // banks each: with the objects 16 banks apart (mod 64) the four objects of a half-wave
+            // cover the 64 banks exactly. (2532 doubles per object put them 36 banks apart: every
+            // access a two- to three-way conflict, LDS busy half of the kernel's time.)
+            while (p.obj_doubles % 32u != 8u) {
+                p.obj_doubles += 2u;
+            }
+        }
         p.blk.assign(static_cast<std::size_t>(p.nrows) * p.row_units * p.ng * 4u, 0u);
         p.ops0.assign(static_cast<std::size_t>(p.nrows) * p.ng, wave_op0{});
+        p.place_level.assign(static_cast<std::size_t>(p.nrows) * p.ng, 0u);
         for (std::uint32_t r = 0; r < p.nrows; ++r) {
             std::uint32_t rk = 0;
             bool wrow = false;
@@ -710,6 +724,7 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
                     put_unit(p.blk, u0 + static_cast<std::size_t>(6u + 2u * k) * p.ng, reinterpret_cast<const char *>(&c) + 16);
                 }
                 p.ops0[static_cast<std::size_t>(r) * p.ng + g] = it.z;
+                p.place_level[static_cast<std::size_t>(r) * p.ng + g] = g < rows[r].size() ? levels[rows[r][g]] : 0u;
             }
         }
         // Lanes per operation: 4 put twice the objects into a wave for the same rows (an object
@@ -866,6 +881,315 @@ void wave_plan_eval(const wave_plan &p, std::uint32_t order, const double state[
     }
 }
 
+std::uint64_t wave_plan_hash(const wave_plan &p)
+{
+    std::uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&h](const void *data, std::size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(data);
+        for (std::size_t i = 0; i < bytes; ++i) {
+            h = (h ^ b[i]) * 0x100000001b3ull;
+        }
+    };
+    mix(p.blk.data(), p.blk_bytes());
+    mix(p.ops0.data(), p.ops0.size() * sizeof(wave_op0));
+    mix(p.rhs, sizeof(p.rhs));
+    const std::uint32_t v[5] = {p.nrows, p.ng, p.nslots, p.one, p.row_units};
+    mix(v, sizeof(v));
+    return h;
+}
+
+// The schedule of a plan with one operation per row (ng = 1) as straight-line HIP source: what
+// k_propagate_wave<.., 1, 8, .., CT> runs in place of its data-driven rows when the dynamics are
+// known when the library is built (profiles/gen_compiled_tapes.py writes csrc/gen/compiled_tapes.hpp
+// from it). Every lane of an object's 8 executes every operation; all 8 store the same result, so
+// no lane ever reads from LDS what another lane wrote and the compiler may interleave the
+// operations of a level freely. Offsets, trip counts, weights and 1 / n are literals; sums whose
+// range is empty at an order are not emitted at all.
+constexpr std::uint32_t EMIT_BATCH_LOADS = 56;
+
+std::string wave_emit_source(const wave_plan &p, std::uint32_t order, int id)
+{
+    std::string o;
+    char buf[640];
+    auto put = [&o, &buf](const char *fmt, auto... args) {
+        std::snprintf(buf, sizeof(buf), fmt, args...);
+        o += buf;
+    };
+    auto lit = [](double v) {
+        char b[64];
+        if (v == 0.) {
+            return std::string("0.");
+        }
+        std::snprintf(b, sizeof(b), "%a", v);
+        return std::string(b);
+    };
+    const std::uint32_t L = order + 1u;
+    auto unit = [&](std::uint32_t r, std::uint32_t u, void *dst, std::size_t bytes) {
+        std::memcpy(dst, p.blk.data() + (static_cast<std::size_t>(r) * p.row_units + u) * 4u, bytes);
+    };
+    auto has_pm = [&](std::uint32_t r) {
+        const wave_op0 &z = p.ops0[r];
+        return z.kind == WK_DIV || z.kind == WK_SQRT || z.kind == WK_POW || z.kind == WK_RDIV || (z.kind == WK_FUSED && z.par >= 0);
+    };
+    // The operations by dependency level: those of a level are independent, so their loads are
+    // written first, then their arithmetic, then their stores -- no store stands between the loads
+    // of a level, and the compiler (which cannot tell Wb + k from Wb + 8 sub + k') may issue them
+    // together instead of waiting for one operation's chain before it starts the next one's.
+    std::uint32_t depth = 0;
+    for (const std::uint32_t l : p.place_level) {
+        depth = std::max(depth, l);
+    }
+    put("// plan hash %016llx: %u operations in %u levels, %u series\n", static_cast<unsigned long long>(wave_plan_hash(p)), p.nrows, depth, p.nslots);
+    put("template <>\n__device__ __forceinline__ void wave_compiled_rows<%d>(char *Wb, int sub, const double *pars, double tmhi)\n{\n", id);
+    o += "    const char *Ws = Wb + 8 * sub, *Wsb = Wb - 8 * sub;\n    const double dsub = static_cast<double>(sub);\n";
+    o += "    (void)pars;\n    (void)tmhi;\n    (void)dsub;\n";
+    for (std::uint32_t r = 0; r < p.nrows; ++r) {
+        if (has_pm(r)) {
+            put("    double pm%u = 1.;\n", r);
+        }
+    }
+    for (std::uint32_t n = 0; n < order; ++n) {
+        put("    // ---- order %u ----\n", n);
+        // Batches: the operations of a level, cut where their operands would exceed EMIT_BATCH_LOADS doubles
+        // (13 operations of one level at order 19 are 300 operands: more than the registers hold).
+        std::vector<std::uint32_t> batch_of(p.nrows, 0u);
+        std::uint32_t nbatch = 0;
+        for (std::uint32_t lv = 1; lv <= depth; ++lv) {
+            std::uint32_t in_batch = 0;
+            ++nbatch;
+            for (std::uint32_t r = 0; r < p.nrows; ++r) {
+                if (p.place_level[r] != lv) {
+                    continue;
+                }
+                wave_hdr h;
+                unit(r, 0, &h, 16);
+                std::uint32_t loads = 2u;
+                for (std::uint32_t k = 0; k < h.nk; ++k) {
+                    wave_conv c;
+                    unit(r, 5u + 2u * k, &c, 16);
+                    const int span = static_cast<int>(n) - static_cast<int>(c.a >> 20);
+                    loads += span >= 0 ? 2u * static_cast<std::uint32_t>(span / 8 + 1) : 0u;
+                }
+                if (in_batch != 0u && in_batch + loads > EMIT_BATCH_LOADS) {
+                    ++nbatch;
+                    in_batch = 0;
+                }
+                in_batch += loads;
+                batch_of[r] = nbatch;
+            }
+        }
+        for (std::uint32_t lv = 1; lv <= nbatch; ++lv) {
+            o += "    {\n";
+            // -- loads --
+            for (std::uint32_t r = 0; r < p.nrows; ++r) {
+                if (batch_of[r] != lv) {
+                    continue;
+                }
+                wave_hdr h;
+                unit(r, 0, &h, 16);
+                const wave_op0 &z = p.ops0[r];
+                for (std::uint32_t k = 0; k < h.nk; ++k) {
+                    wave_conv c;
+                    unit(r, 5u + 2u * k, &c, 16);
+                    const int span = static_cast<int>(n) - static_cast<int>(c.a >> 20);
+                    if (span < 0) {
+                        continue;
+                    }
+                    const long offa = static_cast<long>(c.a & 0xfffffu), offb = static_cast<long>(c.b) + 8l * static_cast<long>(n);
+                    for (int t = 0; t <= span / 8; ++t) {
+                        put("        const double a%u_%u_%d = *reinterpret_cast<const double *>(Ws + %ld), b%u_%u_%d = *reinterpret_cast<const double *>(Wsb + %ld);\n",
+                            r, k, t, offa + 64l * t, r, k, t, offb - 64l * t);
+                    }
+                }
+                for (std::uint32_t m = 0; m < WAVE_LIN_MAX; ++m) {
+                    wave_lin l;
+                    unit(r, 1u + m, &l, 16);
+                    if (l.coef == 0. || (n > 0u && l.off == p.one * L * 8u)) {
+                        continue;
+                    }
+                    put("        const double l%u_%u = *reinterpret_cast<const double *>(Wb + %lu);\n", r, m, static_cast<unsigned long>(l.off + 8u * n));
+                }
+                if (n == 0u && z.kind != WK_FUSED && z.kind != WK_SQRT && z.kind != WK_TIME) {
+                    put("        const double z%u = *reinterpret_cast<const double *>(Wb + %lu);\n", r,
+                        static_cast<unsigned long>(static_cast<std::uint32_t>(z.a) * L * 8u));
+                }
+            }
+            // -- partial sums, written term by term ACROSS the sums of the batch (one dependent chain per sum:
+            // in source order they alternate, which is what a lone wave on its SIMD needs to keep issuing),
+            // then the sums over the 8 lanes, again step by step across the operations --
+            struct conv_ref {
+                std::uint32_t r, k;
+                wave_conv c;
+                int span;
+                bool plain;
+            };
+            std::vector<conv_ref> cvs;
+            std::vector<std::uint32_t> summed;
+            for (std::uint32_t r = 0; r < p.nrows; ++r) {
+                if (batch_of[r] != lv) {
+                    continue;
+                }
+                wave_hdr h;
+                unit(r, 0, &h, 16);
+                put("        double acc%u = 0.;\n", r);
+                bool any_sum = false;
+                for (std::uint32_t k = 0; k < h.nk; ++k) {
+                    conv_ref cr{};
+                    cr.r = r;
+                    cr.k = k;
+                    unit(r, 5u + 2u * k, &cr.c, 16);
+                    unit(r, 6u + 2u * k, reinterpret_cast<char *>(&cr.c) + 16, 16);
+                    cr.span = static_cast<int>(n) - static_cast<int>(cr.c.a >> 20);
+                    if (cr.span < 0) {
+                        continue;
+                    }
+                    cr.plain = cr.c.wa == 0. && cr.c.wb == 0.;
+                    cvs.push_back(cr);
+                    any_sum = true;
+                }
+                if (any_sum) {
+                    summed.push_back(r);
+                }
+            }
+            for (int t = 0; t < 3; ++t) {
+                for (const conv_ref &cr : cvs) {
+                    if (t > cr.span / 8) {
+                        continue;
+                    }
+                    // (the third trip of 8 lanes can leave the 21 coefficients of the series: those lanes are
+                    // masked; everywhere else a lane beyond the range reads a zero on the A side)
+                    const bool mask = 8 * (t + 1) > static_cast<int>(L);
+                    const std::uint32_t r = cr.r, k = cr.k;
+                    if (cr.plain) {
+                        if (t == 0) {
+                            put("        double sk%u_%u = a%u_%u_0 * b%u_%u_0;\n", r, k, r, k, r, k);
+                        } else if (!mask) {
+                            put("        sk%u_%u = fma(a%u_%u_%d, b%u_%u_%d, sk%u_%u);\n", r, k, r, k, t, r, k, t, r, k);
+                        } else {
+                            put("        sk%u_%u = sub <= %d ? fma(a%u_%u_%d, b%u_%u_%d, sk%u_%u) : sk%u_%u;\n", r, k, cr.span - 8 * t, r, k, t, r, k, t, r, k, r, k);
+                        }
+                    } else {
+                        const double ct = static_cast<double>(n) * cr.c.wa + cr.c.wc + 8. * t * cr.c.wb;
+                        std::snprintf(buf, sizeof(buf), "fma(dsub, %s, %s)", lit(cr.c.wb).c_str(), lit(ct).c_str());
+                        const std::string W = buf;
+                        if (t == 0) {
+                            put("        double wk%u_%u = (%s * a%u_%u_0) * b%u_%u_0;\n", r, k, W.c_str(), r, k, r, k);
+                        } else if (!mask) {
+                            put("        wk%u_%u = fma(%s * a%u_%u_%d, b%u_%u_%d, wk%u_%u);\n", r, k, W.c_str(), r, k, t, r, k, t, r, k);
+                        } else {
+                            put("        wk%u_%u = sub <= %d ? fma(%s * a%u_%u_%d, b%u_%u_%d, wk%u_%u) : wk%u_%u;\n", r, k, cr.span - 8 * t, W.c_str(), r, k, t, r, k, t, r, k, r, k);
+                        }
+                    }
+                }
+            }
+            for (const conv_ref &cr : cvs) {
+                if (cr.plain) {
+                    put("        acc%u = fma(%s, sk%u_%u, acc%u);\n", cr.r, lit(cr.c.wc).c_str(), cr.r, cr.k, cr.r);
+                } else {
+                    put("        acc%u += wk%u_%u;\n", cr.r, cr.r, cr.k);
+                }
+            }
+            for (const char *ctrl : {"0xB1", "0x4E", "0x141"}) {
+                for (const std::uint32_t r : summed) {
+                    put("        acc%u += dpp_f64<%s>(acc%u);\n", r, ctrl, r);
+                }
+            }
+            // -- linear terms, the functions (order 0) or the factors, the stores --
+            for (std::uint32_t r = 0; r < p.nrows; ++r) {
+                if (batch_of[r] != lv) {
+                    continue;
+                }
+                wave_hdr h;
+                unit(r, 0, &h, 16);
+                const wave_op0 &z = p.ops0[r];
+                for (std::uint32_t m = 0; m < WAVE_LIN_MAX; ++m) {
+                    wave_lin l;
+                    unit(r, 1u + m, &l, 16);
+                    if (l.coef == 0. || (n > 0u && l.off == p.one * L * 8u)) {
+                        continue;
+                    }
+                    put("        acc%u = fma(%s, l%u_%u, acc%u);\n", r, lit(l.coef).c_str(), r, m, r);
+                }
+                if (n == 0u) {
+                    std::string sv = lit(z.c);
+                    if (z.par >= 0) {
+                        std::snprintf(buf, sizeof(buf), "pars[%d]", z.par);
+                        sv = buf;
+                    }
+                    switch (z.kind) {
+                        case WK_DIV:
+                            put("        pm%u = 1. / z%u;\n        const double res%u = acc%u / z%u;\n", r, r, r, r, r);
+                            break;
+                        case WK_SQRT:
+                            put("        const double res%u = sqrt(acc%u);\n        pm%u = 1. / (2. * res%u);\n", r, r, r, r);
+                            break;
+                        case WK_POW:
+                            put("        pm%u = 1. / z%u;\n        const double res%u = pow_order0(z%u, %s);\n", r, r, r, r, lit(z.c).c_str());
+                            break;
+                        case WK_EXP:
+                            put("        const double res%u = det_exp(z%u);\n", r, r);
+                            break;
+                        case WK_SIN:
+                            put("        const double res%u = sin(z%u);\n", r, r);
+                            break;
+                        case WK_COS:
+                            put("        const double res%u = cos(z%u);\n", r, r);
+                            break;
+                        case WK_RDIV:
+                            put("        pm%u = 1. / z%u;\n        const double res%u = %s / z%u;\n", r, r, r, sv.c_str(), r);
+                            break;
+                        case WK_TIME:
+                            put("        const double res%u = tmhi;\n", r);
+                            break;
+                        default:
+                            if (z.par >= 0) {
+                                put("        pm%u = %s%s;\n        const double res%u = acc%u * pm%u;\n", r, z.pad != 0 ? "1. / " : "", sv.c_str(), r, r, r);
+                            } else {
+                                put("        const double res%u = acc%u;\n", r, r);
+                            }
+                            break;
+                    }
+                } else if (h.flags & WF_TIME) {
+                    put("        const double res%u = %s;\n", r, n == 1u ? "1." : "0.");
+                } else {
+                    std::snprintf(buf, sizeof(buf), "acc%u", r);
+                    std::string e = buf;
+                    if (has_pm(r)) {
+                        std::snprintf(buf, sizeof(buf), "acc%u * pm%u", r, r);
+                        e = buf;
+                    }
+                    if (h.flags & WF_DIVN) {
+                        e = "(" + e + ") * " + lit(1. / static_cast<double>(n));
+                    }
+                    put("        const double res%u = %s;\n", r, e.c_str());
+                }
+            }
+            for (std::uint32_t r = 0; r < p.nrows; ++r) {
+                if (batch_of[r] != lv) {
+                    continue;
+                }
+                wave_hdr h;
+                unit(r, 0, &h, 16);
+                put("        *reinterpret_cast<double *>(Wb + %lu) = res%u;\n", static_cast<unsigned long>(h.dst + 8u * n), r);
+            }
+            o += "    }\n";
+        }
+        // Order n of the right-hand sides gives order n + 1 of the state (every lane, for itself).
+        o += "    {\n";
+        for (int c = 0; c < 7; ++c) {
+            put("        const double s%d = *reinterpret_cast<const double *>(Wb + %lu);\n", c,
+                static_cast<unsigned long>((static_cast<std::uint32_t>(p.rhs[c]) * L + n) * 8u));
+        }
+        for (int c = 0; c < 7; ++c) {
+            put("        *reinterpret_cast<double *>(Wb + %lu) = s%d * %s;\n", static_cast<unsigned long>((static_cast<std::uint32_t>(c) * L + n + 1u) * 8u), c,
+                lit(1. / static_cast<double>(n + 1u)).c_str());
+        }
+        o += "    }\n";
+    }
+    o += "}\n";
+    return o;
+}
+
 hipError_t wave_launch(const wave_plan &plan, const std::uint32_t *d_blk, const wave_op0 *d_ops0, bool events, const prop_params &prm,
                        hipStream_t stream)
 {
@@ -972,4 +1296,25 @@ extern "C" int csc_wave_plan_eval(const void *tape, uint32_t nops, uint32_t nslo
         out_stats[7] = plan.lpg;
     }
     return 0;
+}
+
+// Diagnostic / build tool entry point: the straight-line source of the tape's fused schedule (one
+// operation per row) as wave_compiled_rows<id>; returns the bytes needed (the text is written
+// when it fits `cap`), 0 when the tape has no schedule. *hash: what identifies the schedule at run time.
+extern "C" uint64_t csc_wave_emit_source(const void *tape, uint32_t nops, uint32_t nslots, const int32_t *rhs7, uint32_t order, int id,
+                                         char *out, uint64_t cap, uint64_t *hash)
+{
+    csc::wave_plan plan;
+    if (tape == nullptr || rhs7 == nullptr || !csc::wave_build_plan(static_cast<const csc::tape_op *>(tape), nops, nslots, rhs7, 1, order, plan)
+        || plan.ng != 1u) {
+        return 0;
+    }
+    const std::string src = csc::wave_emit_source(plan, order, id);
+    if (hash != nullptr) {
+        *hash = csc::wave_plan_hash(plan);
+    }
+    if (out != nullptr && src.size() + 1u <= cap) {
+        std::memcpy(out, src.c_str(), src.size() + 1u);
+    }
+    return src.size() + 1u;
 }

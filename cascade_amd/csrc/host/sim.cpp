@@ -659,6 +659,11 @@ void sim::finalise_ctor(options o)
             throw std::invalid_argument("The mu parameter of the dynamics must be finite and positive, but it is "
                                         + fmt_d(o.dyn.mu) + " instead");
         }
+        // J2 + drag keeps its equations' tape as well: below ~49 k objects the library runs it from
+        // the tape's compiled form (8 objects per wave fill the GPU sooner than 64).
+        if (o.dyn.kind == (dynamics::dyn_t::j2 | dynamics::dyn_t::drag) && !o.dyn.eqs.empty()) {
+            m_data->tape = lower_dynamics(o.dyn.eqs);
+        }
     }
     m_data->dyn = o.dyn;
     m_npars = o.dyn.npars;
@@ -1511,7 +1516,8 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     }
     cfg.d_pars = d_pars;
     cfg.npars = m_npars;
-    if (from_tape) {
+    // (the tagged built-ins bring their tape along too: small populations run from its compiled form)
+    if (from_tape || !d.tape.ops.empty()) {
         static_assert(sizeof(tape_op) == sizeof(csc_tape_op), "tape layout");
         cfg.tape = reinterpret_cast<const csc_tape_op *>(d.tape.ops.data());
         cfg.tape_nops = static_cast<std::uint32_t>(d.tape.ops.size());
@@ -1565,7 +1571,7 @@ outcome sim::step_impl(bool upload, const std::function<void()> &confirm)
     // The several-lanes-per-object kernel (k_propagate_wave: tape dynamics at order 20; the
     // hand-unrolled Kepler / J2 / J2 + drag kernels are faster than it) always writes rows: in the first superstep of a configuration the slots are a guess, and a
     // particle that needs more has the pass repeated with what it asked for.
-    const bool wave_ok = d.wave_env && d.order == 20u && !d.tape.ops.empty() && d.dyn.kind == dynamics::dyn_t::tape;
+    const bool wave_ok = d.wave_env && d.order == 20u && !d.tape.ops.empty() && csc_wave_would_run(d.ctx, &cfg, n) != 0;
     const auto rows_fit = [&](std::uint32_t cap) { return static_cast<double>(n) * cap * (xs + vs + 2u) * 8. <= 96e9; };
     if (!sparse && d.single_pass_mode != 0 && wave_ok && d.row_hint == 0u) {
         row_cap = std::max(4u, nchunks0 / 2u + 3u);

@@ -269,10 +269,18 @@ CSC_DEV double group_sum(double v)
     return v;
 }
 
+// Compiled tapes (csrc/gen/compiled_tapes.hpp, written by profiles/gen_compiled_tapes.py from
+// cascade_wave.hip::wave_emit_source): orders 0 .. P - 1 of a schedule with one operation per row as
+// straight-line code, for dynamics known when the library is built. CT = 0: none (the rows are
+// interpreted from the schedule in LDS).
+template <int CT>
+__device__ __forceinline__ void wave_compiled_rows(char *Wb, int sub, const double *pars, double tmhi);
+
 // A workgroup is 1 to 8 waves that share nothing but the copy of the schedule in LDS: after the
 // copy every wave works through its own objects and synchronises with itself only.
-template <int P, int NG, int LPG, bool EVENTS>
-__global__ __launch_bounds__(64 * WAVE_WPB_MAX, 2) void k_propagate_wave(const prop_params prm, const wave_sched sc)
+template <int P, int NG, int LPG, bool EVENTS, int CT = 0>
+// (a compiled tape runs one wave per workgroup and, its series filling the LDS, one wave per SIMD at most: 512 registers)
+__global__ __launch_bounds__(CT != 0 ? 64 : 64 * WAVE_WPB_MAX, CT != 0 ? 1 : 2) void k_propagate_wave(const prop_params prm, const wave_sched sc)
 {
     extern __shared__ double lds[];
     constexpr int L = P + 1;
@@ -295,8 +303,11 @@ __global__ __launch_bounds__(64 * WAVE_WPB_MAX, 2) void k_propagate_wave(const p
     // (the 8 lanes of a group read the same 16 bytes).
     uint4 *lops = reinterpret_cast<uint4 *>(lds + static_cast<std::size_t>(wpb * OPW) * sc.obj_doubles);
     const std::uint32_t RUN = sc.row_units * NG; // 16-byte units per row
-    for (std::uint32_t k = threadIdx.x; k < sc.nrows * RUN; k += blockDim.x) {
-        lops[k] = sc.blk[k];
+    static_assert(CT == 0 || (NG == 1 && LPG == 8), "a compiled tape runs one operation at a time, 8 lanes per object");
+    if constexpr (CT == 0) {
+        for (std::uint32_t k = threadIdx.x; k < sc.nrows * RUN; k += blockDim.x) {
+            lops[k] = sc.blk[k];
+        }
     }
     for (int e = lo; e < static_cast<int>(WAVE_OBJ_PAD); e += LPO) {
         W[e - static_cast<int>(WAVE_OBJ_PAD)] = 0.;
@@ -355,7 +366,11 @@ __global__ __launch_bounds__(64 * WAVE_WPB_MAX, 2) void k_propagate_wave(const p
             const double max_dt = rem.hi > 0. ? rem.hi : 0.;
 
             // ---- orders 0 .. P - 1 of every operation; order n of the right-hand side gives order n + 1 of the state ----
-            for (int n = 0; n < P; ++n) {
+            if constexpr (CT != 0) {
+                wave_compiled_rows<CT>(Wb, sub, pars, tm.hi);
+                wave_lds_sync();
+            }
+            for (int n = 0; CT == 0 && n < P; ++n) {
                 static_assert(P < 31, "wave_rcp");
                 const double dn = static_cast<double>(n), rn = n > 0 ? wave_rcp[n] : 1.;
                 const int trips = __builtin_amdgcn_readfirstlane((n + LPG) / LPG);

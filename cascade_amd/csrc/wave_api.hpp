@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -20,6 +21,7 @@ constexpr std::size_t WAVE_LDS_MAX = 160u * 1024u;
 struct wave_plan {
     std::vector<std::uint32_t> blk; // [nrows][row_units][ng] 16-byte units, 4 words each
     std::vector<wave_op0> ops0;     // [nrows][ng]
+    std::vector<std::uint32_t> place_level; // [nrows][ng]: dependency level of the operation there (0: empty place)
     std::uint32_t nrows = 0, ng = 0, nslots = 0, obj_doubles = 0, row_units = 0, one = 0;
     std::uint32_t lpg = 8;          // lanes that share one operation of a row (4 or 8): an object owns lpg x ng lanes
     std::uint32_t wpb = 1;          // waves of a workgroup (they share the schedule in LDS)
@@ -56,6 +58,14 @@ bool wave_build_plan(const tape_op *tape, std::uint32_t nops, std::uint32_t nslo
 // Launches k_propagate_wave<20, plan.ng, plan.lpg, events> over prm.n objects (the plan's blk / ops0 on the device).
 hipError_t wave_launch(const wave_plan &plan, const std::uint32_t *d_blk, const wave_op0 *d_ops0, bool events, const prop_params &prm,
                        hipStream_t stream);
+// What identifies a schedule (the compiled tapes of csrc/gen/compiled_tapes.hpp are found by it).
+std::uint64_t wave_plan_hash(const wave_plan &plan);
+// Straight-line source of a plan with one operation per row, as wave_compiled_rows<id> (build tool).
+std::string wave_emit_source(const wave_plan &plan, std::uint32_t order, int id);
+// Compiled tapes (cascade_tapes.hip): the id of the schedule with this hash, 0 when there is none;
+// the launch of k_propagate_wave<20, 1, 8, events, id> for a plan with one operation per row.
+int wave_compiled_lookup(std::uint64_t hash);
+hipError_t wave_launch_compiled(int id, const wave_plan &plan, bool events, const prop_params &prm, hipStream_t stream);
 // The plan executed on the host, operation by operation as the kernel does (tests of the fusion
 // and the schedule without a GPU): Taylor coefficients [7][order + 1] of x, y, z, vx, vy, vz, r.
 void wave_plan_eval(const wave_plan &plan, std::uint32_t order, const double state[7], const double *pars, double time, double *out);

@@ -458,6 +458,21 @@ int csc_propagate_range_rows(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n, 
 int csc_wave_plan_eval(const void *tape /* csc_tape_op[nops] */, uint32_t nops, uint32_t nslots, const int32_t *rhs7, int ng,
                        uint32_t order, const double *state7, const double *pars, double time, double *out_coeffs,
                        uint32_t *out_stats);
+/* What a pass with rows (csc_propagate_rows, csc_propagate_range_rows) over n particles would run
+ * for this configuration: 0 the one-lane-per-object kernels, 1 k_propagate_wave interpreting the
+ * fused schedule of cfg->tape, 2 one of its compiled tapes. A caller that guesses row slots for the
+ * first superstep, or shards the propagation, asks here so that every pass of a superstep (and
+ * every process) runs the same arithmetic. No counterpart in the reference. */
+int csc_wave_would_run(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n);
+/* Build tool, no GPU work: the fused schedule of the tape with one operation per row as
+ * straight-line HIP source (a specialisation wave_compiled_rows<id>, see csrc/k_propagate_wave.hpp),
+ * from which profiles/gen_compiled_tapes.py writes csrc/gen/compiled_tapes.hpp for the dynamics
+ * known when the library is built -- the counterpart of heyoka's LLVM JIT in the reference
+ * (src/sim_basic.cpp:553-577 EXTERNAL), ahead of time. Returns the bytes the text needs (it is
+ * written when it fits `cap`; out may be null), 0 when the tape has no such schedule; *hash: what
+ * identifies the schedule at run time. */
+uint64_t csc_wave_emit_source(const void *tape /* csc_tape_op[nops] */, uint32_t nops, uint32_t nslots, const int32_t *rhs7,
+                              uint32_t order, int id, char *out, uint64_t cap, uint64_t *hash);
 size_t csc_shard_record_bytes(uint32_t nchunks);
 int csc_shard_pack(csc_ctx *ctx, uint32_t n, uint32_t first, uint32_t count, uint32_t nchunks, const uint32_t *d_nsub,
                    const int32_t *d_status, const uint32_t *d_ev_idx, const double *d_ev_time, const double *d_nf_last_t,

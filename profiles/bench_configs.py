@@ -23,6 +23,8 @@ unit = 1.0
 if which.startswith("leo_"):
     flags = {"leo_j2drag": dict(C22S22=False), "leo_default": dict(), "leo_full": dict(J3=True, J4=True, sun=True, moon=True, SRP=True)}[which]
     dyn = dynamics.simple_earth(**flags)
+    if os.environ.get("UNTAG"):
+        dyn[0] = dyn[0]  # (the tagged built-ins then run from their tape like any other dynamics)
     st, bstar = leo_si_population(n, seed=42)
     npars = dyn.tape["npars"]
     pars = np.concatenate([bstar, np.full((n, 1), 0.02)], axis=1)[:, :npars].copy()

@@ -116,3 +116,53 @@ def test_random_dynamics_match_the_interpreter(seed, monkeypatch):
     assert t0 == t1 and n0 == n1 and p0 == p1
     assert states_close(s1, s0, 1e-9)
     assert len(c0) == len(c1) and np.array_equal(c0["i"], c1["i"]) and np.array_equal(c0["j"], c1["j"])
+
+
+@pytest.mark.parametrize("which", ["default", "j2drag", "haumea"])
+def test_compiled_tapes_match_the_interpreted_rows(which, monkeypatch):
+    """The dynamics known when the library is built run from straight-line code
+    (cascade_tapes.hip; the tagged J2 + drag below 49 152 objects): same outcomes and counts as the
+    interpreted schedule (CASCADE_WAVE_COMPILED=0), states within 1e-9 of the vector's scale."""
+    from cascade_amd import _capi
+    from cascade_amd import dynamics as D
+    from cascade_amd import sim
+    from cascade_amd.workloads import haumea_dynamics, haumea_ring, leo_si_population
+
+    res = []
+    for compiled in (0, 1):
+        monkeypatch.setenv("CASCADE_WAVE_COMPILED", str(compiled))
+        if which == "haumea":
+            dyn, k = haumea_dynamics()
+            s = sim(haumea_ring(3001), 5000.0, dyn=dyn, n_par_ct=2, reentry_radius=[k["ra"], k["rb"], k["rc"]], exit_radius=k["a_s"] * 10)
+        else:
+            dyn = D.simple_earth(C22S22=(which == "default"))
+            st, bstar = leo_si_population(2501, seed=3)
+            st[:, 6] *= 50.0
+            s = sim(st, 185.5663, dyn=dyn, pars=bstar.copy(), n_par_ct=5, conj_thresh=5000.0, reentry_radius=6378136.3 + 150e3)
+            s.time = 2.5e8
+        ctx = _capi.Context.from_handle(s._hip_context)
+        out = []
+        for k in range(4):
+            if k == 1:
+                ctx.profile(True)
+                ctx.profile_reset()
+            oc = s.step()
+            ii = s.interrupt_info
+            out.append((oc.name, ii, s.time, s.state.copy(), s.last_bp_pairs, s.last_total_substeps))
+            if oc.name in ("reentry", "exit"):
+                s.remove_particles([ii])
+            elif oc.name == "collision":
+                s.remove_particles(list(ii))
+        kernels = set(ctx.profile_get())
+        # (the tagged J2 + drag runs on its unrolled kernel when the compiled tapes are off)
+        assert ("k_propagate_wave" in kernels) == (compiled == 1 or which != "j2drag"), kernels
+        res.append(out)
+    for (gn, gi, gt, gs, gp, gsub), (wn, wi, wt, ws, wp, wsub) in zip(res[1], res[0]):
+        assert gn == wn
+        if isinstance(wi, (tuple, list)) and len(wi) == 2 and isinstance(wi[1], float):
+            assert gi[0] == wi[0] and abs(gi[1] - wi[1]) <= 1e-9 * max(1.0, abs(wi[1]))
+        else:
+            assert gi == wi
+        assert abs(gt - wt) <= 1e-9 * max(1.0, abs(wt))
+        assert gs.shape == ws.shape and states_close(gs, ws, 1e-9)
+        assert gp == wp and gsub == wsub

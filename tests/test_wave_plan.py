@@ -107,3 +107,31 @@ def test_plan_rejects_a_tape_that_assigns_twice():
     rc = lib.csc_wave_plan_eval(ops.ctypes.data, len(ops), int(tape["nslots"]), rhs.ctypes.data, 0, ORDER, st.ctypes.data, st.ctypes.data,
                                 C.c_double(0.0), out.ctypes.data, None)
     assert rc == 2
+
+
+def test_compiled_tapes_header_is_current():
+    """cascade_amd/csrc/gen/compiled_tapes.hpp (generated, committed) holds the straight-line code of
+    the schedules the fusion produces TODAY for the built-in dynamics: same hashes in its table, same
+    text. (A stale entry would never run -- schedules are found by hash -- but silently fall back on
+    the interpreted rows.)"""
+    import importlib.util
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_compiled_tapes", os.path.join(root, "profiles", "gen_compiled_tapes.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    from cascade_amd import _capi
+
+    lib = _capi.lib()
+    text = open(os.path.join(root, "cascade_amd", "csrc", "gen", "compiled_tapes.hpp")).read()
+    table = {int(i): int(h, 16) for h, i in re.findall(r"\{0x([0-9a-f]{16})ull, (\d+)\}", text)}
+    seen = 0
+    for ident, _, dyn in gen.tapes():
+        src, h = gen.emit(lib, dyn, ident)
+        assert src is not None
+        assert table.get(ident) == h, "profiles/gen_compiled_tapes.py has to be run again (tape %d)" % ident
+        assert src in text, "profiles/gen_compiled_tapes.py has to be run again (text of tape %d)" % ident
+        seen += 1
+    assert seen == len(table) >= 3
