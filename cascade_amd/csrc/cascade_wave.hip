@@ -905,7 +905,7 @@ std::uint64_t wave_plan_hash(const wave_plan &p)
 // no lane ever reads from LDS what another lane wrote and the compiler may interleave the
 // operations of a level freely. Offsets, trip counts, weights and 1 / n are literals; sums whose
 // range is empty at an order are not emitted at all.
-constexpr std::uint32_t EMIT_BATCH_LOADS = 56;
+constexpr std::uint32_t EMIT_BATCH_LOADS = 56; // (36: 8.3 / 5.3 / 0.63 ms for default / J2 + drag / Haumea; 56: 7.9 / 3.6 / 0.48; 76: 7.8 / 3.6 / 0.59; 112: 9.7 / 3.6 / 0.46)
 
 std::string wave_emit_source(const wave_plan &p, std::uint32_t order, int id)
 {
