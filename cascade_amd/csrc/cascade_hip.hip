@@ -147,6 +147,9 @@ struct csc_ctx {
     csc::wave_plan wave_plan1;
     int wave_compiled = 0;
     bool wave_uploaded = false; // (the interpreted schedule is on the device)
+    // A schedule without an ahead-of-time tape is compiled at first use (hipRTC; CASCADE_WAVE_JIT=0: never);
+    // wave_jit: 0 no, 1 the plan with one operation per row fits, -1 the compilation failed (interpreted rows from then on).
+    int wave_jit = 0;
     int wave_mode = -1;
     bool pass1_wave = false; // the last pass 1 ran k_propagate_wave: the store pass then does too (same substeps)
     float4 *na_scratch = nullptr;       // device address of `scratch` on this context's device
@@ -1358,6 +1361,7 @@ static int wave_select(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n_total, 
                                               cfg->tape_rhs, 0, cfg->order, ctx->wave_plan);
         ctx->wave_compiled = 0;
         ctx->wave_uploaded = false;
+        ctx->wave_jit = 0;
         const char *ce = std::getenv("CASCADE_WAVE_COMPILED");
         if (!(ce && std::atoi(ce) == 0) && !std::getenv("CASCADE_WAVE_NG")
             && csc::wave_build_plan(reinterpret_cast<const csc::tape_op *>(cfg->tape), cfg->tape_nops, cfg->tape_nslots, cfg->tape_rhs, 1,
@@ -1366,6 +1370,15 @@ static int wave_select(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n_total, 
             const size_t granted = (ctx->wave_plan1.wave_bytes() + 2047u) / 2048u * 2048u;
             if (csc::WAVE_LDS_MAX / granted >= 2u) {
                 ctx->wave_compiled = csc::wave_compiled_lookup(csc::wave_plan_hash(ctx->wave_plan1));
+                // (2: also for the dynamics that have an ahead-of-time tape, to compare the two)
+                const char *je = std::getenv("CASCADE_WAVE_JIT");
+                const int jv = je ? std::atoi(je) : 1;
+                if (jv == 2 && cfg->dyn_kind == CSC_DYN_TAPE) {
+                    ctx->wave_compiled = 0;
+                }
+                if (ctx->wave_compiled == 0 && jv != 0) {
+                    ctx->wave_jit = 1;
+                }
             }
         }
         if (std::getenv("CASCADE_WAVE_DEBUG")) {
@@ -1381,6 +1394,9 @@ static int wave_select(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n_total, 
     if (ctx->wave_compiled != 0) {
         return 2;
     }
+    if (ctx->wave_jit == 1) {
+        return 3;
+    }
     // Two waves per compute unit at least: with less, the one-lane-per-object interpreter with its
     // global workspace is the faster one.
     if (!ctx->wave_fits || (ctx->wave_plan.waves_per_cu() < 2u && !std::getenv("CASCADE_WAVE_NG"))) {
@@ -1395,7 +1411,24 @@ static int wave_select(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n_total, 
 static int wave_try_launch(csc_ctx *ctx, const csc_prop_cfg *cfg, const csc::prop_params &p, bool events, bool &launched)
 {
     launched = false;
-    const int how = wave_select(ctx, cfg, p.n_total != 0u ? p.n_total : p.n);
+    int how = wave_select(ctx, cfg, p.n_total != 0u ? p.n_total : p.n);
+    if (how == 3) {
+        std::string jerr;
+        hipError_t jrc = hipSuccess;
+        KT(p.nsub_in ? "k_propagate_wave_store" : "k_propagate_wave",
+           jrc = csc::wave_launch_jit(ctx->wave_plan1, cfg->order, events, p, ctx->stream, jerr));
+        if (jrc == hipSuccess) {
+            launched = true;
+            return CSC_OK;
+        }
+        if (jrc != hipErrorNotSupported) {
+            return ctx->fail(jrc, "k_propagate_wave (run-time compiled tape) launch");
+        }
+        // (no compiler, no headers, a source it rejects: said once, then the interpreted rows)
+        std::fprintf(stderr, "cascade: run-time compilation of the dynamics failed, the interpreted schedule runs instead: %s\n", jerr.c_str());
+        ctx->wave_jit = -1;
+        how = wave_select(ctx, cfg, p.n_total != 0u ? p.n_total : p.n);
+    }
     if (how == 0) {
         return CSC_OK;
     }

@@ -24,10 +24,29 @@
 #endif
 
 
+#ifdef __HIPCC_RTC__
+// Run-time compilation (hipRTC: the compiled tapes of user dynamics): the HIP runtime header is
+// built in and the C++ standard headers are not available; these are the few names used from them.
+namespace std
+{
+using int8_t = signed char;
+using uint8_t = unsigned char;
+using int32_t = int;
+using uint32_t = unsigned int;
+using int64_t = long long;
+using uint64_t = unsigned long long;
+using size_t = decltype(sizeof(0));
+} // namespace std
+#define DBL_MAX __DBL_MAX__
+#define DBL_MIN __DBL_MIN__
+#define DBL_EPSILON __DBL_EPSILON__
+#define FLT_MAX __FLT_MAX__
+#else
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
 #include <cstdint>
+#endif
 
 namespace csc
 {

@@ -66,6 +66,11 @@ std::string wave_emit_source(const wave_plan &plan, std::uint32_t order, int id)
 // the launch of k_propagate_wave<20, 1, 8, events, id> for a plan with one operation per row.
 int wave_compiled_lookup(std::uint64_t hash);
 hipError_t wave_launch_compiled(int id, const wave_plan &plan, bool events, const prop_params &prm, hipStream_t stream);
+// Run-time compilation (cascade_tapes.hip; CASCADE_WAVE_JIT=0 switches it off): the same kernel for a schedule that has
+// no ahead-of-time tape, compiled by hipRTC at first use, kept for the life of the process.
+// hipErrorNotSupported with `err` set when it cannot be built (the caller falls back on the interpreted rows).
+hipError_t wave_launch_jit(const wave_plan &plan, std::uint32_t order, bool events, const prop_params &prm, hipStream_t stream,
+                           std::string &err);
 // The plan executed on the host, operation by operation as the kernel does (tests of the fusion
 // and the schedule without a GPU): Taylor coefficients [7][order + 1] of x, y, z, vx, vy, vz, r.
 void wave_plan_eval(const wave_plan &plan, std::uint32_t order, const double state[7], const double *pars, double time, double *out);

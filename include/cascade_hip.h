@@ -460,7 +460,8 @@ int csc_wave_plan_eval(const void *tape /* csc_tape_op[nops] */, uint32_t nops, 
                        uint32_t *out_stats);
 /* What a pass with rows (csc_propagate_rows, csc_propagate_range_rows) over n particles would run
  * for this configuration: 0 the one-lane-per-object kernels, 1 k_propagate_wave interpreting the
- * fused schedule of cfg->tape, 2 one of its compiled tapes. A caller that guesses row slots for the
+ * fused schedule of cfg->tape, 2 one of its compiled tapes, 3 a tape compiled at run time (hipRTC, at
+ * the first launch; environment CASCADE_WAVE_JIT=0 switches that off). A caller that guesses row slots for the
  * first superstep, or shards the propagation, asks here so that every pass of a superstep (and
  * every process) runs the same arithmetic. No counterpart in the reference. */
 int csc_wave_would_run(csc_ctx *ctx, const csc_prop_cfg *cfg, uint32_t n);

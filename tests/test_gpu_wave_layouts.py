@@ -166,3 +166,44 @@ def test_compiled_tapes_match_the_interpreted_rows(which, monkeypatch):
         assert abs(gt - wt) <= 1e-9 * max(1.0, abs(wt))
         assert gs.shape == ws.shape and states_close(gs, ws, 1e-9)
         assert gp == wp and gsub == wsub
+
+
+@pytest.mark.timeout(400)
+def test_run_time_compiled_tape_matches_the_interpreted_rows(monkeypatch, capfd):
+    """CASCADE_WAVE_JIT=1: dynamics without an ahead-of-time tape are compiled by hipRTC at first
+    use (cascade_tapes.hip, half a minute per kernel variant) and run from straight-line code: same
+    counts and pairs as the interpreted schedule, states within 1e-9 of the vector's scale."""
+    from cascade_amd import _capi, sim
+    from cascade_amd.workloads import random_leo_pop_kep
+    from test_wave_plan_fuzz import _random_dynamics
+
+    seed = 12  # (not one of test_random_dynamics_match_the_interpreter: a compiled kernel lives as long as the process)
+    dyn = _random_dynamics(seed)
+    npars = dyn.tape["npars"]
+    n = 1501
+    st = random_leo_pop_kep(n, seed=seed)
+    pars = np.random.default_rng(seed).uniform(0.5, 1.5, (n, max(1, npars)))[:, :npars].copy()
+    monkeypatch.setenv("CASCADE_WAVE_DEBUG", "1")
+    res = []
+    for jit in (0, 1):
+        monkeypatch.setenv("CASCADE_WAVE_JIT", str(jit))
+        kw = dict(dyn=dyn, n_par_ct=3, conj_thresh=1e-2, min_coll_radius=float("inf"))
+        if npars:
+            kw["pars"] = pars
+        s = sim(st.copy(), 0.23, **kw)
+        s.time = 0.37
+        ctx = _capi.Context.from_handle(s._hip_context)
+        ctx.profile(True)
+        ctx.profile_reset()
+        capfd.readouterr()
+        for _ in range(3):
+            assert s.step().name == "success"
+        err = capfd.readouterr().err
+        assert "k_propagate_wave" in set(ctx.profile_get())
+        assert ("[wave] run-time compilation: ok" in err) == bool(jit), err
+        assert "interpreted schedule runs instead" not in err, err
+        res.append((s.state.copy(), s.time, s.last_bp_pairs, s.last_total_substeps, s.conjunctions.copy()))
+    (s0, t0, p0, n0, c0), (s1, t1, p1, n1, c1) = res
+    assert t0 == t1 and n0 == n1 and p0 == p1
+    assert states_close(s1, s0, 1e-9)
+    assert len(c0) == len(c1) and np.array_equal(c0["i"], c1["i"]) and np.array_equal(c0["j"], c1["j"])
