@@ -520,8 +520,11 @@ CSC_DEV void dt_tile_decode(unsigned long long rec, bool valid, dt_tile_in &t)
     t.c = valid ? static_cast<std::uint32_t>(rec >> 56) : 0u;
 }
 
+// (four waves per SIMD: 128 registers. The kernel waits on dependent instructions more than on
+// anything else -- see DESIGN.md 3.4 -- and the fused variant with two groups of records in flight
+// per trip of its filter needed 152: 6.0 ms per launch of the bench against 5.4 with one group.)
 template <int TL, bool FUSE = false>
-__global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_params q)
+__global__ __launch_bounds__(64 * DT_TILE_WAVES, 4) void k_bp_tiles(const dual_params q)
 {
     constexpr int TPW = 64 / TL;
     constexpr std::uint32_t BUF = 64u * TL; // what one batch can yield at most
@@ -569,18 +572,20 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
                 atomicAdd(q.fuse_cnt + shard * DT_CTR_STRIDE, fill);
                 *fillp = 0u;
             }
-            // (two groups of 64 pairs per trip: the record gathers of both are in flight together.)
+            // (FG groups of 64 pairs per trip, their record gathers in flight together: two cost a wave
+            // per SIMD in registers, which costs more than the gathers' latency -- see above.)
             // The survivors are compacted to the front of the buffer -- never ahead of the read
             // position -- and leave with ONE atomic per flush: with conjunction tracking a twentieth
             // of the pairs survives, and one atomic per group of 64 on the list's counter is 5e6
             // same-address atomics per superstep of 10M objects, ~10 ns each, serialised.
             std::uint32_t nsurv = 0;
-            for (std::uint32_t k0 = 0; k0 < fill; k0 += 128u) {
-                bool keep[2];
-                unsigned long long rec[2];
-                float4 ra[2][4], rb[2][4];
+            constexpr int FG = 1;
+            for (std::uint32_t k0 = 0; k0 < fill; k0 += 64u * FG) {
+                bool keep[FG];
+                unsigned long long rec[FG];
+                float4 ra[FG][4], rb[FG][4];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < FG; ++g) {
                     const std::uint32_t k = k0 + 64u * g + lane;
                     keep[g] = k < fill;
                     rec[g] = buf[keep[g] ? k : k0];
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(64 * DT_TILE_WAVES) void k_bp_tiles(const dual_para
                 }
                 wave_sync(); // (every lane has read its two records of the buffer)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < FG; ++g) {
                     keep[g] = keep[g] && chord_keep_recs(ra[g], rb[g], q.thr_extra);
                     const unsigned long long km = __ballot(keep[g]);
                     if (keep[g]) {
