@@ -104,7 +104,7 @@ struct jit_kernel {
 };
 
 std::mutex jit_mutex;
-std::map<std::pair<std::uint64_t, int>, jit_kernel> jit_cache; // (schedule hash, events) per process (one device kind)
+std::map<std::pair<std::uint64_t, int>, jit_kernel> jit_cache; // (schedule hash, events + 2 x device): a module belongs to the device it was loaded on
 
 std::string lib_dir()
 {
@@ -189,7 +189,11 @@ hipError_t wave_launch_jit(const wave_plan &plan, std::uint32_t order, bool even
     hipFunction_t fn = nullptr;
     {
         std::lock_guard<std::mutex> lock(jit_mutex);
-        const auto key = std::make_pair(wave_plan_hash(plan), events ? 1 : 0);
+        int dev = 0;
+        if (const hipError_t rc = hipGetDevice(&dev); rc != hipSuccess) {
+            return rc;
+        }
+        const auto key = std::make_pair(wave_plan_hash(plan), (events ? 1 : 0) + 2 * dev);
         auto it = jit_cache.find(key);
         if (it == jit_cache.end()) {
             it = jit_cache.emplace(key, jit_kernel{}).first;
