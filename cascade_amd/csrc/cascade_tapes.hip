@@ -119,7 +119,9 @@ std::string lib_dir()
 
 void jit_build(const wave_plan &plan, std::uint32_t order, bool events, jit_kernel &out)
 {
-    const std::string inc = lib_dir() + "/csrc";
+    // (the kernel headers: csrc/ beside the shared library, or where CASCADE_JIT_INCLUDE_DIR says)
+    const char *inc_env = std::getenv("CASCADE_JIT_INCLUDE_DIR");
+    const std::string inc = inc_env ? std::string(inc_env) : lib_dir() + "/csrc";
     for (const char *h : {"/dev_math.hpp", "/k_propagate.hpp", "/k_propagate_wave.hpp"}) {
         if (!std::ifstream(inc + h)) {
             out.err = "run-time compilation needs the kernel headers in " + inc + " (" + (h + 1) + " is missing)";

@@ -207,3 +207,46 @@ def test_run_time_compiled_tape_matches_the_interpreted_rows(monkeypatch, capfd)
     assert t0 == t1 and n0 == n1 and p0 == p1
     assert states_close(s1, s0, 1e-9)
     assert len(c0) == len(c1) and np.array_equal(c0["i"], c1["i"]) and np.array_equal(c0["j"], c1["j"])
+
+
+@pytest.mark.timeout(400)
+def test_failed_run_time_compilation_falls_back_to_the_interpreted_rows(monkeypatch, capfd, tmp_path):
+    """When the tape cannot be compiled (here: the kernel headers are not where the library is told
+    to look) the library says so once and the interpreted schedule runs: same results as with
+    run-time compilation switched off."""
+    from cascade_amd import _capi, sim
+    from cascade_amd.workloads import random_leo_pop_kep
+    from test_wave_plan_fuzz import _random_dynamics
+
+    seed = 13  # (a schedule no other test compiles: a failure is remembered per schedule too)
+    dyn = _random_dynamics(seed)
+    npars = dyn.tape["npars"]
+    n = 901
+    st = random_leo_pop_kep(n, seed=seed)
+    pars = np.random.default_rng(seed).uniform(0.5, 1.5, (n, max(1, npars)))[:, :npars].copy()
+    res = []
+    for broken in (0, 1):
+        if broken:
+            monkeypatch.setenv("CASCADE_WAVE_JIT", "1")
+            monkeypatch.setenv("CASCADE_JIT_INCLUDE_DIR", str(tmp_path))
+        else:
+            monkeypatch.setenv("CASCADE_WAVE_JIT", "0")
+        kw = dict(dyn=dyn, n_par_ct=3, conj_thresh=1e-2, min_coll_radius=float("inf"))
+        if npars:
+            kw["pars"] = pars
+        s = sim(st.copy(), 0.23, **kw)
+        s.time = 0.37
+        ctx = _capi.Context.from_handle(s._hip_context)
+        ctx.profile(True)
+        ctx.profile_reset()
+        capfd.readouterr()
+        for _ in range(3):
+            assert s.step().name == "success"
+        err = capfd.readouterr().err
+        assert "k_propagate_wave" in set(ctx.profile_get())
+        assert (err.count("interpreted schedule runs instead") == 1) == bool(broken), err
+        res.append((s.state.copy(), s.time, s.last_bp_pairs, s.last_total_substeps, s.conjunctions.copy()))
+    (s0, t0, p0, n0, c0), (s1, t1, p1, n1, c1) = res
+    assert t0 == t1 and n0 == n1 and p0 == p1
+    assert np.array_equal(s0, s1)
+    assert len(c0) == len(c1) and np.array_equal(c0["i"], c1["i"]) and np.array_equal(c0["j"], c1["j"])
