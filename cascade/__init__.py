@@ -1,8 +1,8 @@
 """``import cascade``: the reference's package name (cascade.py/__init__.py:47-61) over the
 MI355X-native implementation in ``cascade_amd`` -- ``cascade.sim``, ``cascade.outcome``,
-``cascade.dynamics.kepler`` / ``simple_earth``, ``cascade.set_nthreads`` / ``get_nthreads`` and the
-six ``cascade.set_logger_level_*``. ``cascade.dynamics.mascon_asteroid`` (heyoka's mascon model)
-and ``cascade.test`` are not part of this build."""
+``cascade.dynamics.kepler`` / ``simple_earth`` / ``mascon_asteroid`` / ``mascon_asteroid_energy``,
+``cascade.set_nthreads`` / ``get_nthreads`` and the six ``cascade.set_logger_level_*``.
+``cascade.test`` is not part of this build."""
 import sys as _sys
 
 import cascade_amd as _impl
