@@ -229,6 +229,25 @@ def main():
             assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
             assert np.array_equal(full.state, part.state) and full.time == part.time
             assert part.last_propagated <= -(-301 // world)
+
+        # User dynamics (a random right-hand side of tests/test_wave_plan_fuzz.py): every process
+        # compiles the tape's straight-line kernel itself (hipRTC) and integrates its range with it.
+        from test_wave_plan_fuzz import _random_dynamics
+
+        dyn = _random_dynamics(12)
+        npars = dyn.tape["npars"]
+        st = random_leo_pop_kep(501, seed=12)
+        pars = np.random.default_rng(12).uniform(0.5, 1.5, (501, max(1, npars)))[:, :npars].copy()
+        kw = dict(dyn=dyn, n_par_ct=3, conj_thresh=1e-2, min_coll_radius=float("inf"), device=dev)
+        if npars:
+            kw["pars"] = pars
+        full = sim(st.copy(), 0.23, **kw)
+        part = shard(sim(st.copy(), 0.23, **kw), propagation=True)
+        for _ in range(3):
+            of, op = full.step(), part.step()
+            assert of == op and full.interrupt_info == part.interrupt_info, (rank, of, op)
+            assert np.array_equal(full.state, part.state) and full.time == part.time
+        assert gather_conjunctions(part).tobytes() == full.conjunctions.tobytes()
         print("simprop ok", rank)
     elif mode == "simerr":
         # An error that only ONE process can see -- the global box of chunk 1 overflows f32, the
